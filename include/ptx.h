@@ -1,0 +1,155 @@
+/*
+ * ptx.h -- C ABI of libptx_hip.so: the MI355X (gfx950) progressive path tracer.
+ *
+ * This is the drop-in boundary for the hot path of aminequirogabritos/path-tracing.  The reference has
+ * no FFI; the seam it replaces is the implicit WebGL contract between main.js and
+ * shaders/fragmentShaderPathTracing.glsl.  Each entry point cites the reference call
+ * site it stands in for (paths relative to /root/reference).  Plain pointers and sizes only; the caller
+ * keeps ownership of everything it passes in; nothing here retains host pointers after returning.
+ *
+ * Conventions: functions return PTX_OK (0) or a negative ptx_status; the message of the last failure is
+ * available from ptx_last_error().  No exception crosses the ABI.  A context is bound to ONE GPU and is
+ * not thread-safe (the reference host is single-threaded JS, main.js:262,391).  Multi-GPU = one context
+ * (one process) per GPU, each rendering its own frames, summed by the caller with one all-reduce of the
+ * accumulation buffer (ptx_accum_export_device / ptx_accum_import_device; DESIGN.md "Multi-GPU").
+ * There is no CPU fallback: every entry point fails with PTX_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef PTX_H
+#define PTX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ptx_ctx ptx_ctx;
+
+typedef enum ptx_status {
+    PTX_OK = 0,
+    PTX_ERR_INVALID = -1, /* bad argument (NULL, size mismatch, index out of range) */
+    PTX_ERR_HIP = -2,     /* a HIP runtime call failed; message in ptx_last_error   */
+    PTX_ERR_STATE = -3,   /* call order: scene / params not set yet                 */
+    PTX_ERR_NOMEM = -4
+} ptx_status;
+
+/*
+ * The eleven data textures main.js:272-282 uploads with utils/textureUploader.js:4 (coordinatesTexture,
+ * normalsTexture, colorsTexture, emissionsTexture, lightIndicesTexture, nodesBoundingBoxesMins,
+ * nodesBoundingBoxesMaxs, nodesMissLinkIndices, nodesInorderTrianglesIndices, nodesTrianglesCount,
+ * inorderTrianglesIndicesArray), de-triplicated and typed (the reference stores every integer as a
+ * float copied into r,g,b: classes/bvh.js:284-293, main.js:187-190, utils/triangleMapper.js:62-64).
+ */
+typedef struct ptx_scene {
+    uint32_t T; /* triangles       (uniform triangleCount,     main.js:298) */
+    uint32_t N; /* BVH nodes       (uniform bvhNodeCount,      main.js:305) */
+    uint32_t L; /* light triangles (uniform lightIndicesCount, main.js:299) */
+    const float *coords;        /* 9T: a.xyz b.xyz c.xyz per triangle, world space            */
+    const float *normals;       /* 3T: geometric normal per triangle (main.js:652-653)        */
+    const float *colors;        /* 3T: material.color                                          */
+    const float *emissions;     /* 3T: material.emissive * 50 (utils/triangleMapper.js:44,60)  */
+    const int32_t *light_tri;   /* L : indices of triangles with any emissive channel > 0      */
+    const float *node_min;      /* 3N: AABB min per node, pre-order (classes/bvh.js:282)       */
+    const float *node_max;      /* 3N: AABB max per node                                       */
+    const int32_t *node_miss;   /* N : miss link = pre-order index after the subtree, -1 = end */
+    const int32_t *node_first;  /* N : leaf: first slot in inorder_tri; internal: -2           */
+    const int32_t *node_count;  /* N : leaf: triangle count; internal: 0                       */
+    const int32_t *inorder_tri; /* T : triangle indices, leaf lists concatenated in pre-order  */
+} ptx_scene;
+
+/*
+ * The gl.uniform* block of main.js:290-308 that the shader actually reads.  aspectRatio is derived as
+ * the reference does (JS double width/height rounded to f32, main.js:291).  Not needed: cameraDirection,
+ * vertexCount, totalFrames, quadX, quadY, quadSize, maxTextureSize (addressing / tiling only).
+ */
+typedef struct ptx_params {
+    uint32_t width, height;   /* uniform windowSize */
+    float cam_src[3];         /* cameraSource       */
+    float cam_up[3];          /* cameraUp           */
+    float cam_right[3];       /* cameraRight        */
+    float cam_left_bottom[3]; /* cameraLeftBottom   */
+    int32_t max_path_length;  /* maxPathLength      */
+    int32_t sample_count;     /* sampleCount (paths per pixel per frame) */
+} ptx_params;
+
+/* Work counters since the last ptx_reset_counters (new; for Mrays/s and the roofline). */
+typedef struct ptx_counters {
+    uint64_t samples;        /* camera paths (get_ray_radiance calls, glsl:404)                          */
+    uint64_t rays;           /* closest-hit queries the REFERENCE algorithm issues for those samples     */
+    uint64_t rays_traced;    /* traversals actually executed (primary-hit cache + shadow-ray memo remove some) */
+    uint64_t node_visits;    /* box tests actually executed   (only with option "count" = 1, else 0)     */
+    uint64_t tri_tests;      /* triangle tests actually executed (only with option "count" = 1)          */
+    uint64_t ray_hits;       /* reference-equivalent rays that hit something                             */
+    uint64_t light_attempts; /* iterations of sample_random_light's loop (glsl:372)                      */
+    uint64_t pixel_frames;   /* (pixel, frame) results accumulated                                       */
+    uint64_t kernel_launches;/* launches of the path-tracing kernel                                      */
+    double kernel_ms;        /* HIP-event time of those launches, summed (valid after ptx_synchronize)   */
+} ptx_counters;
+
+/* ---- lifecycle (no reference counterpart: canvas.getContext('webgl2'), main.js:123) ---- */
+int ptx_device_count(void);
+/* device_ids: HIP device ordinals; n_devices must be 1 (one context per GPU). Returns NULL on failure
+ * (see ptx_last_error(NULL)). */
+ptx_ctx *ptx_create(const int *device_ids, int n_devices);
+void ptx_destroy(ptx_ctx *ctx);
+const char *ptx_last_error(const ptx_ctx *ctx); /* ctx may be NULL: last creation error */
+
+/* ---- scene + parameters ---- */
+/* Replaces the 11 uploadTexture() calls per frame of main.js:272-282 (done once here). Validates every
+ * index (miss links, leaf ranges, triangle and light indices) before anything reaches the GPU. */
+int ptx_upload_scene(ptx_ctx *ctx, const ptx_scene *scene);
+/* Replaces the uniform block of main.js:290-308. Resets the accumulation when the size changes. */
+int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
+/* Tuning / test switches (no reference counterpart). Keys:
+ *   "traversal" : 0 = literal threaded traversal of glsl:207-249 (every box-hit node visited),
+ *                 1 = same traversal + conservative best-t pruning (default; identical results)
+ *   "memo"      : 1 = reuse the per-pixel primary hit and the last light-attempt ray for the shadow ray
+ *                 (default; both are bit-identical rays in the reference), 0 = trace every ray
+ *   "count"     : 1 = also count node visits / triangle tests (slower), 0 = off (default)
+ *   "pipeline"  : 0 = one-kernel-per-batch path tracer, 1 = wavefront queues (default when available)
+ *   "frame_batch": max frames rendered concurrently (0 = auto)
+ */
+int ptx_set_option(ptx_ctx *ctx, const char *key, int64_t value);
+
+/* ---- rendering ---- */
+/* Replaces the per-frame draw of main.js:330-355 (gl.drawArrays per 32x32 tile + sleeps) for n_frames
+ * frames: frame f runs sample_count paths per pixel seeded with timestamps[f] (uniform timestamp,
+ * main.js:300; glsl:520) and adds clamp(mean, 0, 1) (glsl:526-529) to the float accumulation buffer, in
+ * frame order.  first_frame_number mirrors uniform frameNumber (main.js:303) and is only book-keeping
+ * here: the running mean sum/frames_done equals the reference's mix(prev, cur, 1/(frameNumber+1)) chain
+ * (glsl:537-540) without its RGBA8 rounding.  Asynchronous: work is queued on the context's stream. */
+int ptx_render_frames(ptx_ctx *ctx, const int32_t *timestamps, uint32_t n_frames, uint32_t first_frame_number);
+int ptx_synchronize(ptx_ctx *ctx);
+/* Replaces gl.clear of the ping-pong targets (main.js:326-327) / starting a new progressive render. */
+int ptx_reset_accum(ptx_ctx *ctx);
+int ptx_frames_done(const ptx_ctx *ctx); /* frames accumulated so far (negative status on error) */
+
+/* ---- read-back (replaces gl.readPixels, main.js:459) ---- */
+/* rgb: W*H*3 floats, row 0 = bottom row like GL. Running mean of the accumulated frames. */
+int ptx_read_linear_f32(ptx_ctx *ctx, float *rgb);
+/* rgb: W*H*3 floats: the raw sum over frames (what the multi-GPU all-reduce adds up). */
+int ptx_read_sum_f32(ptx_ctx *ctx, float *rgb);
+/* out: W*H*4 bytes. apply_gamma: pow(c, 1/2.2) as shaders/fragmentShaderOutput.glsl:35; flip_y: the
+ * vertical flip of main.js:464-473 (row 0 = top row). Quantisation: floor(c*255 + 0.5). */
+int ptx_read_rgba8(ptx_ctx *ctx, uint8_t *out, int apply_gamma, int flip_y);
+
+/* ---- parity / roofline hooks (new) ---- */
+/* Closest hit of n rays (o, d: 3n floats) by ray_bvh_intersection_hit_miss (glsl:207-249). A miss gives
+ * t = 1e38f, tri_id = -1; a hit gives the ORIGINAL triangle index (inorder_tri[k]) of the winner. */
+int ptx_trace_closest(ptx_ctx *ctx, const float *o, const float *d, uint32_t n, float *t, int32_t *tri_id);
+/* Primary-ray closest hits for every pixel (glsl:501-514 + 207-249); W*H entries, row 0 = bottom. */
+int ptx_primary_hits(ptx_ctx *ctx, int32_t *tri_id, float *t);
+/* Primary ray directions (glsl:145-148, 501-514); dirs: W*H*3 floats. */
+int ptx_primary_dirs(ptx_ctx *ctx, float *dirs);
+int ptx_get_counters(ptx_ctx *ctx, ptx_counters *out); /* synchronises */
+int ptx_reset_counters(ptx_ctx *ctx);
+
+/* ---- multi-process reduction hooks (new) ---- */
+/* Device-to-device copy of the W*H*4 f32 accumulation buffer (rgb sum + unused 4th lane) to / from
+ * caller-owned device memory (e.g. a torch tensor that torch.distributed all-reduces over RCCL). */
+int ptx_accum_export_device(ptx_ctx *ctx, void *d_dst);
+int ptx_accum_import_device(ptx_ctx *ctx, const void *d_src, uint32_t frames_done);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_H */

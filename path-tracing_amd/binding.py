@@ -1,0 +1,233 @@
+"""ctypes mirror of the C ABI in include/ptx.h (libptx_hip.so).
+
+The class follows the boundary of SURVEY.md 8b one-to-one: Context.upload_scene ~ the eleven
+uploadTexture() calls (main.js:272-282), set_params ~ the uniform block (main.js:290-308),
+render_frames ~ the per-frame draw (main.js:330-355), read_* ~ gl.readPixels (main.js:459).
+There is no fallback: if the HIP library is missing or no gfx950 device is usable, this raises.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PTX_OK, PTX_ERR_INVALID, PTX_ERR_HIP, PTX_ERR_STATE, PTX_ERR_NOMEM = 0, -1, -2, -3, -4
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int32)
+
+# every symbol include/ptx.h declares (tests check the library exports all of them)
+SYMBOLS = ["ptx_device_count", "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_upload_scene", "ptx_set_params",
+           "ptx_set_option", "ptx_render_frames", "ptx_synchronize", "ptx_reset_accum", "ptx_frames_done",
+           "ptx_read_linear_f32", "ptx_read_sum_f32", "ptx_read_rgba8", "ptx_trace_closest", "ptx_primary_hits",
+           "ptx_primary_dirs", "ptx_get_counters", "ptx_reset_counters", "ptx_accum_export_device",
+           "ptx_accum_import_device"]
+
+
+class PtxError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"ptx status {status}: {message}")
+        self.status = status
+
+
+class CScene(C.Structure):
+    _fields_ = [("T", C.c_uint32), ("N", C.c_uint32), ("L", C.c_uint32), ("coords", _f), ("normals", _f), ("colors", _f),
+                ("emissions", _f), ("light_tri", _i), ("node_min", _f), ("node_max", _f), ("node_miss", _i),
+                ("node_first", _i), ("node_count", _i), ("inorder_tri", _i)]
+
+
+class CParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("cam_src", C.c_float * 3), ("cam_up", C.c_float * 3),
+                ("cam_right", C.c_float * 3), ("cam_left_bottom", C.c_float * 3), ("max_path_length", C.c_int32),
+                ("sample_count", C.c_int32)]
+
+
+class CCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "rays_traced", "node_visits", "tri_tests", "ray_hits",
+                                          "light_attempts", "pixel_frames", "kernel_launches")] + [("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: (float(getattr(self, n)) if n == "kernel_ms" else int(getattr(self, n))) for n, _ in self._fields_}
+
+
+def lib_path():
+    return os.path.join(_HERE, "csrc", "libptx_hip.so")
+
+
+def load_library():
+    """Loads csrc/libptx_hip.so (built in-tree by csrc/Makefile / __graft_entry__.build()).
+
+    torch bundles its own libamdhip64.so; if torch is going to share the process it must be imported
+    BEFORE this library so both resolve to one HIP runtime (DESIGN.md "One HIP runtime per process")."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: run `make -C path-tracing_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    if "torch" not in sys.modules and os.environ.get("PTX_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401  (plumbing only: makes its bundled HIP runtime the process's single one)
+        except Exception:
+            pass
+    L = C.CDLL(path)
+    L.ptx_create.restype = C.c_void_p
+    L.ptx_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.ptx_destroy.argtypes = [C.c_void_p]
+    L.ptx_destroy.restype = None
+    L.ptx_last_error.restype = C.c_char_p
+    L.ptx_last_error.argtypes = [C.c_void_p]
+    L.ptx_upload_scene.argtypes = [C.c_void_p, C.POINTER(CScene)]
+    L.ptx_set_params.argtypes = [C.c_void_p, C.POINTER(CParams)]
+    L.ptx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.ptx_render_frames.argtypes = [C.c_void_p, _i, C.c_uint32, C.c_uint32]
+    L.ptx_synchronize.argtypes = [C.c_void_p]
+    L.ptx_reset_accum.argtypes = [C.c_void_p]
+    L.ptx_frames_done.argtypes = [C.c_void_p]
+    L.ptx_read_linear_f32.argtypes = [C.c_void_p, _f]
+    L.ptx_read_sum_f32.argtypes = [C.c_void_p, _f]
+    L.ptx_read_rgba8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    L.ptx_trace_closest.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, _i]
+    L.ptx_primary_hits.argtypes = [C.c_void_p, _i, _f]
+    L.ptx_primary_dirs.argtypes = [C.c_void_p, _f]
+    L.ptx_get_counters.argtypes = [C.c_void_p, C.POINTER(CCounters)]
+    L.ptx_reset_counters.argtypes = [C.c_void_p]
+    L.ptx_accum_export_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.ptx_accum_import_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    _LIB = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_i)
+
+
+class Context:
+    """One GPU, one scene, one progressive accumulation (ptx_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        ids = (C.c_int * 1)(int(device))
+        self._h = self._lib.ptx_create(ids, 1)
+        if not self._h:
+            raise PtxError(PTX_ERR_HIP, self._lib.ptx_last_error(None).decode())
+        self.params = None
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ptx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != PTX_OK:
+            raise PtxError(rc, self._lib.ptx_last_error(self._h).decode())
+
+    # ---- scene + parameters
+    def upload_scene(self, s):
+        cs = CScene(s.T, s.N, s.L, _fp(s.coords), _fp(s.normals), _fp(s.colors), _fp(s.emissions), _ip(s.light_tri),
+                    _fp(s.node_min), _fp(s.node_max), _ip(s.node_miss), _ip(s.node_first), _ip(s.node_count), _ip(s.inorder_tri))
+        self._check(self._lib.ptx_upload_scene(self._h, C.byref(cs)))
+
+    def set_params(self, p):
+        cp = CParams()
+        cp.width, cp.height = p.width, p.height
+        for k in ("cam_src", "cam_up", "cam_right", "cam_left_bottom"):
+            getattr(cp, k)[:] = [float(x) for x in getattr(p, k)]
+        cp.max_path_length, cp.sample_count = p.max_path_length, p.sample_count
+        self._check(self._lib.ptx_set_params(self._h, C.byref(cp)))
+        self.params = p
+
+    def set_option(self, key, value):
+        self._check(self._lib.ptx_set_option(self._h, key.encode(), int(value)))
+
+    # ---- rendering
+    def render_frames(self, timestamps, first_frame_number=0):
+        ts = np.ascontiguousarray(timestamps, dtype=np.int32)
+        self._check(self._lib.ptx_render_frames(self._h, _ip(ts), ts.size, first_frame_number))
+
+    def synchronize(self):
+        self._check(self._lib.ptx_synchronize(self._h))
+
+    def reset_accum(self):
+        self._check(self._lib.ptx_reset_accum(self._h))
+
+    @property
+    def frames_done(self):
+        return self._lib.ptx_frames_done(self._h)
+
+    # ---- read-back (row 0 = bottom row, like gl.readPixels)
+    def _img(self, ch, dtype):
+        return np.zeros((self.params.height, self.params.width, ch), dtype=dtype)
+
+    def read_linear(self):
+        out = self._img(3, np.float32)
+        self._check(self._lib.ptx_read_linear_f32(self._h, _fp(out)))
+        return out
+
+    def read_sum(self):
+        out = self._img(3, np.float32)
+        self._check(self._lib.ptx_read_sum_f32(self._h, _fp(out)))
+        return out
+
+    def read_rgba8(self, apply_gamma=True, flip_y=True):
+        out = self._img(4, np.uint8)
+        self._check(self._lib.ptx_read_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), int(apply_gamma), int(flip_y)))
+        return out
+
+    # ---- parity / roofline hooks
+    def trace_closest(self, o, d):
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        if o.shape != d.shape:
+            raise ValueError("o and d must have the same shape")
+        n = o.shape[0]
+        t = np.zeros(n, dtype=np.float32)
+        tri = np.zeros(n, dtype=np.int32)
+        self._check(self._lib.ptx_trace_closest(self._h, _fp(o), _fp(d), n, _fp(t), _ip(tri)))
+        return t, tri
+
+    def primary_hits(self):
+        tri = np.zeros((self.params.height, self.params.width), dtype=np.int32)
+        t = np.zeros((self.params.height, self.params.width), dtype=np.float32)
+        self._check(self._lib.ptx_primary_hits(self._h, _ip(tri), _fp(t)))
+        return t, tri
+
+    def primary_dirs(self):
+        out = self._img(3, np.float32)
+        self._check(self._lib.ptx_primary_dirs(self._h, _fp(out)))
+        return out
+
+    def counters(self):
+        c = CCounters()
+        self._check(self._lib.ptx_get_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(self._lib.ptx_reset_counters(self._h))
+
+    # ---- multi-process reduction hooks
+    def accum_export_device(self, device_ptr):
+        self._check(self._lib.ptx_accum_export_device(self._h, C.c_void_p(int(device_ptr))))
+
+    def accum_import_device(self, device_ptr, frames_done):
+        self._check(self._lib.ptx_accum_import_device(self._h, C.c_void_p(int(device_ptr)), int(frames_done)))

@@ -1,0 +1,115 @@
+// ptx_device.h -- device-side arithmetic of the path tracer (gfx950, wave64).
+//
+// Every function restates one piece of /root/reference/shaders/fragmentShaderPathTracing.glsl ("glsl:")
+// as separately rounded IEEE binary32 operations.  The translation unit MUST be compiled with
+// -ffp-contract=off (no FMA contraction) and without any fast-math flag; hipcc's default correctly
+// rounded f32 divide / sqrt are relied upon.  Operation orders follow the arithmetic contract verified
+// against the verbatim shader on SwiftShader:
+//   dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z ; cross as written below ; normalize(v) = v * (1/sqrt(dot))
+//   min/max = IEEE minNum/maxNum (v_min_f32 / v_max_f32) ; sin/cos = the fixed polynomial below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptx {
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 mk(float4 v) { return mk(v.x, v.y, v.z); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+__device__ __forceinline__ float length(V3 a) { return __fsqrt_rn(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / __fsqrt_rn(dot(a, a))); }
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ bool any_ne(V3 a, V3 b) { return a.x != b.x || a.y != b.y || a.z != b.z; }
+
+#define PTX_M_PI 3.141592653589793238462643f   // glsl:2
+#define PTX_M_1_PI 0.3183098861837907f         // glsl:3
+
+// glsl:302-313 (PCG2D).  Returns vec2(seed) * 2^-32.
+__device__ __forceinline__ void pcg2d(uint32_t& sx, uint32_t& sy, float& r0, float& r1) {
+    sx = 1664525u * sx + 1013904223u;
+    sy = 1664525u * sy + 1013904223u;
+    sx += 1664525u * sy;
+    sy += 1664525u * sx;
+    sx ^= sx >> 16;
+    sy ^= sy >> 16;
+    sx += 1664525u * sy;
+    sy += 1664525u * sx;
+    sx ^= sx >> 16;
+    sy ^= sy >> 16;
+    r0 = (float)sx * 2.32830643654e-10f;
+    r1 = (float)sy * 2.32830643654e-10f;
+}
+
+// sincos contract: theta in [0, 2pi]; q = nearest multiple of pi/2; 3-constant Cody-Waite
+// reduction; cephes single-precision polynomials on [-pi/4, pi/4]; every op separately rounded.
+__device__ __forceinline__ void sincos_2pi(float theta, float& s, float& c) {
+    const float TWO_OVER_PI = 0.636619772367581343f;
+    const float P1 = 1.5703125f, P2 = 4.837512969970703125e-4f, P3 = 7.54978995489188216e-8f;
+    int q = (int)(theta * TWO_OVER_PI + 0.5f);
+    float fq = (float)q;
+    float y = ((theta - fq * P1) - fq * P2) - fq * P3;
+    float z = y * y;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * y + y;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    int k = q & 3;
+    float a = (k & 1) ? cp : sp;
+    float b = (k & 1) ? sp : cp;
+    s = (k & 2) ? -a : a;
+    c = (k == 1 || k == 2) ? -b : b;
+}
+
+// glsl:315-337
+__device__ __forceinline__ V3 sample_hemisphere(float r0, float r1, V3 n) {
+    float theta = (2.0f * PTX_M_PI) * r0;
+    float r = __fsqrt_rn(r1);
+    float sn, cs;
+    sincos_2pi(theta, sn, cs);
+    float x = r * cs;
+    float y = r * sn;
+    float z = __fsqrt_rn(1.0f - r * r);
+    V3 major = fabsf(n.x) < 0.57735026919f ? mk(1.f, 0.f, 0.f) : (fabsf(n.y) < 0.57735026919f ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f));
+    V3 u = normalize(cross(n, major));
+    V3 v = cross(n, u);
+    V3 dir = (u * x + v * y) + n * z;
+    return normalize(dir);
+}
+
+// glsl:175-191 with the reciprocal hoisted out (inv = 1.0f / d, computed once per ray; same value).
+__device__ __forceinline__ bool slab_test(V3 o, V3 inv, V3 bmin, V3 bmax, float& tNear) {
+    V3 t1 = (bmin - o) * inv;
+    V3 t2 = (bmax - o) * inv;
+    float tn = fmaxf(fmaxf(fminf(t1.x, t2.x), fminf(t1.y, t2.y)), fminf(t1.z, t2.z));
+    float tf = fminf(fminf(fmaxf(t1.x, t2.x), fmaxf(t1.y, t2.y)), fmaxf(t1.z, t2.z));
+    tNear = tn;
+    return (tn <= tf) && (tf > 0.0f);
+}
+
+// glsl:150-173 with edge1 = v1 - v0 and edge2 = v2 - v0 precomputed (same f32 values).
+__device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float& t_out) {
+    V3 h = cross(d, e2);
+    float a = dot(e1, h);
+    if (a > -0.0001f && a < 0.0001f) return false;
+    float f = 1.0f / a;
+    V3 s = o - v0;
+    float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q = cross(s, e1);
+    float v = f * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = f * dot(e2, q);
+    if (t > 0.0001f) { t_out = t; return true; }
+    return false;
+}
+
+} // namespace ptx

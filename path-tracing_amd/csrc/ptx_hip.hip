@@ -1,0 +1,622 @@
+// ptx_hip.hip -- libptx_hip.so: C ABI (include/ptx.h) + kernels of the MI355X progressive path tracer.
+//
+// Build (see csrc/Makefile):  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+// -ffp-contract=off is part of the numerical contract (ptx_device.h): both the device code and the
+// host-side precomputation below (edges, light pdf, aspect) must round every operation separately.
+#include "../../include/ptx.h"
+#include "ptx_render.h"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ptx;
+
+// ------------------------------------------------------------------------------------------ kernels
+
+// Primary-hit cache: one thread per pixel, 8x8 tiles (glsl:501-514 + 207-249).
+template <bool PRUNE>
+__global__ __launch_bounds__(64) void k_primary(DScene S, DParams P, float* __restrict__ prim_t, int* __restrict__ prim_tri,
+                                                float4* __restrict__ dirs) {
+    uint32_t px, py;
+    if (!tile_pixel(P, blockIdx.x, threadIdx.x, px, py)) return;
+    const V3 d = primary_dir(P, px, py);
+    LocalCnt c = {};
+    float t; int tri;
+    closest_hit<PRUNE, false>(S, P.src, d, t, tri, c);
+    const size_t i = (size_t)py * P.W + px;
+    prim_t[i] = t;
+    prim_tri[i] = tri;
+    if (dirs) dirs[i] = make_float4(d.x, d.y, d.z, 0.f);
+}
+
+// Test hook: closest hit of arbitrary rays (glsl:207-249), one thread per ray.
+template <bool PRUNE>
+__global__ __launch_bounds__(64) void k_trace(DScene S, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
+                                              float* __restrict__ t_out, int* __restrict__ tri_out, unsigned long long* counters) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    LocalCnt c = {};
+    if (i < n) {
+        float t; int tri;
+        c.rays = c.rays_traced = 1;
+        if (closest_hit<PRUNE, true>(S, mk(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2]),
+                                     mk(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2]), t, tri, c)) c.ray_hits = 1;
+        t_out[i] = t;
+        tri_out[i] = tri;
+    }
+    flush_counters(c, counters, 0);
+}
+
+// The path tracer: one thread per (pixel, frame-in-batch); one wave = one 8x8 pixel tile of one frame.
+// Writes the frame's clamp(mean) into fb[frame][pixel]; k_accumulate folds the batch in frame order.
+template <bool PRUNE, bool MEMO, bool COUNT>
+__global__ __launch_bounds__(64) void k_render(DScene S, DParams P, const int32_t* __restrict__ timestamps,
+                                               const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
+                                               float4* __restrict__ fb, unsigned long long* counters) {
+    uint32_t px, py;
+    const bool valid = tile_pixel(P, blockIdx.x, threadIdx.x, px, py);
+    const uint32_t frame = blockIdx.y;
+    LocalCnt c = {};
+    if (valid) {
+        const size_t i = (size_t)py * P.W + px;
+        const V3 rgb = render_pixel_frame<PRUNE, MEMO, COUNT>(S, P, px, py, timestamps[frame], prim_t[i], prim_tri[i], c);
+        fb[(size_t)frame * P.W * P.H + i] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+    }
+    flush_counters(c, counters, valid ? 1u : 0u);
+}
+
+// accum[p] = ((accum[p] + fb[0][p]) + fb[1][p]) + ...   (frame order => independent of the batch size)
+__global__ __launch_bounds__(256) void k_accumulate(float4* __restrict__ accum, const float4* __restrict__ fb, uint32_t npix, uint32_t nframes) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= npix) return;
+    float4 a = accum[p];
+    for (uint32_t f = 0; f < nframes; f++) {
+        const float4 v = fb[(size_t)f * npix + p];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    accum[p] = a;
+}
+
+// Display pass (shaders/fragmentShaderOutput.glsl:22-41) + RGBA8 pack + optional flip (main.js:464-473).
+__global__ __launch_bounds__(256) void k_pack_rgba8(const float4* __restrict__ accum, uint32_t W, uint32_t H, float inv_frames_is_div,
+                                                    int apply_gamma, int flip_y, uchar4* __restrict__ out) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= W * H) return;
+    const uint32_t x = p % W, y = p / W;
+    const float4 a = accum[p];
+    float v[3] = {a.x / inv_frames_is_div, a.y / inv_frames_is_div, a.z / inv_frames_is_div};
+    unsigned char q[3];
+    for (int k = 0; k < 3; k++) {
+        float cval = clamp01(v[k]);
+        if (apply_gamma) cval = powf(cval, 1.0f / 2.2f);
+        q[k] = (unsigned char)floorf(clamp01(cval) * 255.0f + 0.5f);
+    }
+    const uint32_t oy = flip_y ? (H - 1 - y) : y;
+    out[(size_t)oy * W + x] = make_uchar4(q[0], q[1], q[2], 255);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+
+struct ptx_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene
+    bool have_scene = false;
+    DScene S = {};
+    std::vector<void*> scene_allocs;
+
+    // params
+    bool have_params = false;
+    DParams P = {};
+    bool prim_valid = false;
+    float* d_prim_t = nullptr;
+    int* d_prim_tri = nullptr;
+    float4* d_accum = nullptr;
+    uint32_t frames_done = 0;
+
+    // batch frame buffers
+    float4* d_fb = nullptr;
+    size_t fb_frames = 0;
+    int32_t* d_ts = nullptr;
+    size_t ts_cap = 0;
+
+    // options
+    int opt_traversal = 1, opt_memo = 1, opt_count = 0, opt_pipeline = 0, opt_frame_batch = 0;
+
+    // counters + timing
+    unsigned long long* d_counters = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<hipEvent_t> free_events;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+};
+
+static std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                               \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+            return PTX_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+
+static int fail(ptx_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" int ptx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" ptx_ctx* ptx_create(const int* device_ids, int n_devices) {
+    if (!device_ids || n_devices != 1) {
+        g_create_error = "ptx_create: exactly one device per context (multi-GPU = one context per GPU)";
+        return nullptr;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("ptx_create: no HIP device: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    if (device_ids[0] < 0 || device_ids[0] >= count) {
+        g_create_error = "ptx_create: device id out of range";
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_ids[0])) != hipSuccess) {
+        g_create_error = std::string("ptx_create: hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return nullptr;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("ptx_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return nullptr;
+    }
+    ptx_ctx* ctx = new ptx_ctx();
+    ctx->device = device_ids[0];
+    if ((e = hipSetDevice(ctx->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&ctx->d_counters, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long))) != hipSuccess) {
+        g_create_error = std::string("ptx_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+static void free_scene(ptx_ctx* ctx) {
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->have_scene = false;
+    ctx->prim_valid = false;
+}
+
+static void free_params_buffers(ptx_ctx* ctx) {
+    if (ctx->d_prim_t) (void)hipFree(ctx->d_prim_t);
+    if (ctx->d_prim_tri) (void)hipFree(ctx->d_prim_tri);
+    if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+    ctx->d_prim_t = nullptr; ctx->d_prim_tri = nullptr; ctx->d_accum = nullptr; ctx->d_fb = nullptr;
+    ctx->fb_frames = 0;
+    ctx->prim_valid = false;
+}
+
+extern "C" void ptx_destroy(ptx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    free_params_buffers(ctx);
+    if (ctx->d_ts) (void)hipFree(ctx->d_ts);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (auto& pr : ctx->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto ev : ctx->free_events) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+template <typename T>
+static int upload(ptx_ctx* ctx, const std::vector<T>& h, const T** out) {
+    void* p = nullptr;
+    const size_t bytes = (h.empty() ? 1 : h.size()) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    ctx->scene_allocs.push_back(p);
+    if (!h.empty()) HIP_TRY(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)p;
+    return PTX_OK;
+}
+
+extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!sc) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: scene is NULL");
+    const uint32_t T = sc->T, N = sc->N, L = sc->L;
+    if (T == 0 || N == 0) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: T and N must be > 0");
+    if (T >= (1u << 24)) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: T must be < 2^24 (the reference's float-encoded indices share this limit)");
+    if (!sc->coords || !sc->normals || !sc->colors || !sc->emissions || !sc->node_min || !sc->node_max || !sc->node_miss ||
+        !sc->node_first || !sc->node_count || !sc->inorder_tri || (L > 0 && !sc->light_tri))
+        return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: NULL array");
+    // ---- validate every index before it can reach a kernel (a bad miss link would never terminate)
+    for (uint32_t i = 0; i < N; i++) {
+        const int32_t m = sc->node_miss[i];
+        if (!(m == -1 || (m > (int32_t)i && m < (int32_t)N))) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: node_miss[" + std::to_string(i) + "] must be -1 or a later node index");
+        const int32_t f = sc->node_first[i], cnt = sc->node_count[i];
+        if (f == -2) continue;
+        if (f < 0 || cnt < 0 || cnt > 127 || (uint64_t)f + (uint64_t)cnt > T)
+            return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: leaf range of node " + std::to_string(i) + " is out of bounds (count must be <= 127)");
+    }
+    for (uint32_t k = 0; k < T; k++)
+        if (sc->inorder_tri[k] < 0 || (uint32_t)sc->inorder_tri[k] >= T) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: inorder_tri out of range");
+    for (uint32_t l = 0; l < L; l++)
+        if (sc->light_tri[l] < 0 || (uint32_t)sc->light_tri[l] >= T) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: light_tri out of range");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    std::vector<float4> nodeA(N), nodeB(N), v0(T), e1(T), e2(T), aN(T), aC(T), aE(T), light((size_t)L * 6);
+    auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    for (uint32_t i = 0; i < N; i++) {
+        const float* mn = sc->node_min + 3 * (size_t)i;
+        const float* mx = sc->node_max + 3 * (size_t)i;
+        const int32_t f = sc->node_first[i];
+        const int32_t fc = (f == -2) ? -2 : (f | (sc->node_count[i] << 24));
+        nodeA[i] = make_float4(mn[0], mn[1], mn[2], bits(sc->node_miss[i]));
+        nodeB[i] = make_float4(mx[0], mx[1], mx[2], bits(fc));
+    }
+    for (uint32_t k = 0; k < T; k++) {
+        const int32_t tri = sc->inorder_tri[k];
+        const float* p = sc->coords + 9 * (size_t)tri;
+        v0[k] = make_float4(p[0], p[1], p[2], bits(tri));
+        e1[k] = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.f); // glsl:151
+        e2[k] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.f); // glsl:152
+    }
+    for (uint32_t t = 0; t < T; t++) {
+        aN[t] = make_float4(sc->normals[3 * (size_t)t], sc->normals[3 * (size_t)t + 1], sc->normals[3 * (size_t)t + 2], 0.f);
+        aC[t] = make_float4(sc->colors[3 * (size_t)t], sc->colors[3 * (size_t)t + 1], sc->colors[3 * (size_t)t + 2], 0.f);
+        aE[t] = make_float4(sc->emissions[3 * (size_t)t], sc->emissions[3 * (size_t)t + 1], sc->emissions[3 * (size_t)t + 2], 0.f);
+    }
+    for (uint32_t l = 0; l < L; l++) {
+        const int32_t tri = sc->light_tri[l];
+        const float* p = sc->coords + 9 * (size_t)tri;
+        // glsl:390-392: lightArea = 0.5 * length(cross(v1 - v0, v2 - v0)); pdf = 1 / (float(L) * lightArea)
+        const float ax = p[3] - p[0], ay = p[4] - p[1], az = p[5] - p[2];
+        const float bx = p[6] - p[0], by = p[7] - p[1], bz = p[8] - p[2];
+        const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
+        const float area = 0.5f * std::sqrt((cx * cx + cy * cy) + cz * cz);
+        const float pdf = 1.0f / ((float)L * area);
+        light[6 * (size_t)l + 0] = make_float4(p[0], p[1], p[2], 0.f);
+        light[6 * (size_t)l + 1] = make_float4(p[3], p[4], p[5], 0.f);
+        light[6 * (size_t)l + 2] = make_float4(p[6], p[7], p[8], 0.f);
+        light[6 * (size_t)l + 3] = aN[tri];
+        light[6 * (size_t)l + 4] = aE[tri];
+        light[6 * (size_t)l + 5] = make_float4(pdf, area, 0.f, 0.f);
+    }
+    DScene S = {};
+    int rc;
+    if ((rc = upload(ctx, nodeA, &S.nodeA)) || (rc = upload(ctx, nodeB, &S.nodeB)) || (rc = upload(ctx, v0, &S.triV0)) ||
+        (rc = upload(ctx, e1, &S.triE1)) || (rc = upload(ctx, e2, &S.triE2)) || (rc = upload(ctx, aN, &S.attrN)) ||
+        (rc = upload(ctx, aC, &S.attrC)) || (rc = upload(ctx, aE, &S.attrE)) || (rc = upload(ctx, light, &S.light))) {
+        free_scene(ctx);
+        return rc;
+    }
+    S.N = (int)N; S.T = (int)T; S.L = (int)L;
+    ctx->S = S;
+    ctx->have_scene = true;
+    ctx->prim_valid = false;
+    return PTX_OK;
+}
+
+extern "C" int ptx_reset_accum(ptx_ctx* ctx) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_reset_accum: ptx_set_params first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), ctx->stream));
+    ctx->frames_done = 0;
+    return PTX_OK;
+}
+
+extern "C" int ptx_set_params(ptx_ctx* ctx, const ptx_params* p) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!p) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: params is NULL");
+    if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height > (1ull << 28)) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: bad image size");
+    if (p->sample_count < 1) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: sample_count must be >= 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const bool resize = !ctx->have_params || ctx->P.W != p->width || ctx->P.H != p->height;
+    DParams P = {};
+    P.W = p->width; P.H = p->height;
+    P.src = {p->cam_src[0], p->cam_src[1], p->cam_src[2]};
+    P.up = {p->cam_up[0], p->cam_up[1], p->cam_up[2]};
+    P.right = {p->cam_right[0], p->cam_right[1], p->cam_right[2]};
+    P.lb = {p->cam_left_bottom[0], p->cam_left_bottom[1], p->cam_left_bottom[2]};
+    P.aspect = (float)((double)p->width / (double)p->height); // main.js:291
+    P.max_len = p->max_path_length;
+    P.spp = p->sample_count;
+    if (resize) {
+        free_params_buffers(ctx);
+        const size_t npix = (size_t)P.W * P.H;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_prim_t, npix * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_prim_tri, npix * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_accum, npix * sizeof(float4)));
+    }
+    ctx->P = P;
+    ctx->have_params = true;
+    ctx->prim_valid = false;
+    if (resize) return ptx_reset_accum(ctx);
+    return PTX_OK;
+}
+
+extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return PTX_ERR_INVALID;
+    const std::string k(key);
+    if (k == "traversal" && (value == 0 || value == 1)) { ctx->opt_traversal = (int)value; ctx->prim_valid = false; }
+    else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
+    else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
+    else if (k == "pipeline" && (value == 0 || value == 1)) ctx->opt_pipeline = (int)value;
+    else if (k == "frame_batch" && value >= 0 && value <= 4096) ctx->opt_frame_batch = (int)value;
+    else return fail(ctx, PTX_ERR_INVALID, "ptx_set_option: unknown key or bad value: " + k);
+    return PTX_OK;
+}
+
+static int ensure_primary(ptx_ctx* ctx, float4* d_dirs) {
+    if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "scene and params must be set first");
+    if (ctx->prim_valid && !d_dirs) return PTX_OK;
+    const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
+    if (ctx->opt_traversal)
+        hipLaunchKernelGGL(k_primary<true>, dim3(tiles), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
+    else
+        hipLaunchKernelGGL(k_primary<false>, dim3(tiles), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->prim_valid = true;
+    return PTX_OK;
+}
+
+static hipEvent_t get_event(ptx_ctx* ctx) {
+    if (!ctx->free_events.empty()) { hipEvent_t e = ctx->free_events.back(); ctx->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static void drain_events(ptx_ctx* ctx) { // stream must be idle
+    for (auto& pr : ctx->pending_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->kernel_ms += ms;
+        ctx->free_events.push_back(pr.first);
+        ctx->free_events.push_back(pr.second);
+    }
+    ctx->pending_events.clear();
+}
+
+template <bool PRUNE, bool MEMO, bool COUNT>
+static void launch_render(ptx_ctx* ctx, uint32_t tiles, uint32_t nf) {
+    hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_ts, ctx->d_prim_t,
+                       ctx->d_prim_tri, ctx->d_fb, ctx->d_counters);
+}
+
+extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!timestamps && n_frames) return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames: timestamps is NULL");
+    (void)first_frame_number;
+    if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_render_frames: scene and params must be set first");
+    if (n_frames == 0) return PTX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_primary(ctx, nullptr);
+    if (rc) return rc;
+
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    // frames rendered concurrently: bounded by an 8 GiB frame-buffer budget (HBM is 288 GB) and 65535 grid.y
+    size_t batch = ctx->opt_frame_batch > 0 ? (size_t)ctx->opt_frame_batch : std::min<size_t>(64, std::max<size_t>(1, (8ull << 30) / (npix * sizeof(float4))));
+    batch = std::min<size_t>(batch, n_frames);
+    if (ctx->fb_frames < batch) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+        ctx->d_fb = nullptr; ctx->fb_frames = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_fb, batch * npix * sizeof(float4)));
+        ctx->fb_frames = batch;
+    }
+    if (ctx->ts_cap < n_frames) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_ts) (void)hipFree(ctx->d_ts);
+        ctx->d_ts = nullptr; ctx->ts_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_ts, (size_t)n_frames * sizeof(int32_t)));
+        ctx->ts_cap = n_frames;
+    }
+    const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += (uint32_t)batch) {
+        const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
+        // pageable source: the runtime stages the copy before returning, so the caller's array is free to go
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ts, timestamps + f0, nf * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        const int sel = (ctx->opt_traversal ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
+        switch (sel) {
+            case 0: launch_render<false, false, false>(ctx, tiles, nf); break;
+            case 1: launch_render<false, false, true>(ctx, tiles, nf); break;
+            case 2: launch_render<false, true, false>(ctx, tiles, nf); break;
+            case 3: launch_render<false, true, true>(ctx, tiles, nf); break;
+            case 4: launch_render<true, false, false>(ctx, tiles, nf); break;
+            case 5: launch_render<true, false, true>(ctx, tiles, nf); break;
+            case 6: launch_render<true, true, false>(ctx, tiles, nf); break;
+            default: launch_render<true, true, true>(ctx, tiles, nf); break;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        ctx->pending_events.emplace_back(e0, e1);
+        ctx->kernel_launches++;
+        hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->d_fb, (uint32_t)npix, nf);
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->frames_done += nf;
+    }
+    return PTX_OK;
+}
+
+extern "C" int ptx_synchronize(ptx_ctx* ctx) {
+    if (!ctx) return PTX_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    return PTX_OK;
+}
+
+extern "C" int ptx_frames_done(const ptx_ctx* ctx) { return ctx ? (int)ctx->frames_done : PTX_ERR_INVALID; }
+
+static int read_accum(ptx_ctx* ctx, std::vector<float4>& h) {
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
+    int rc = ptx_synchronize(ctx);
+    if (rc) return rc;
+    h.resize((size_t)ctx->P.W * ctx->P.H);
+    HIP_TRY(ctx, hipMemcpy(h.data(), ctx->d_accum, h.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+extern "C" int ptx_read_sum_f32(ptx_ctx* ctx, float* rgb) {
+    if (!ctx || !rgb) return PTX_ERR_INVALID;
+    std::vector<float4> h;
+    int rc = read_accum(ctx, h);
+    if (rc) return rc;
+    for (size_t i = 0; i < h.size(); i++) { rgb[3 * i] = h[i].x; rgb[3 * i + 1] = h[i].y; rgb[3 * i + 2] = h[i].z; }
+    return PTX_OK;
+}
+
+extern "C" int ptx_read_linear_f32(ptx_ctx* ctx, float* rgb) {
+    if (!ctx || !rgb) return PTX_ERR_INVALID;
+    std::vector<float4> h;
+    int rc = read_accum(ctx, h);
+    if (rc) return rc;
+    const float nf = (float)(ctx->frames_done ? ctx->frames_done : 1);
+    for (size_t i = 0; i < h.size(); i++) { rgb[3 * i] = h[i].x / nf; rgb[3 * i + 1] = h[i].y / nf; rgb[3 * i + 2] = h[i].z / nf; }
+    return PTX_OK;
+}
+
+extern "C" int ptx_read_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int flip_y) {
+    if (!ctx || !out) return PTX_ERR_INVALID;
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    uchar4* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_out, npix * sizeof(uchar4)));
+    const float nf = (float)(ctx->frames_done ? ctx->frames_done : 1);
+    hipLaunchKernelGGL(k_pack_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->P.W, ctx->P.H, nf, apply_gamma, flip_y, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, npix * sizeof(uchar4), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_read_rgba8: ") + hipGetErrorString(e));
+    drain_events(ctx);
+    return PTX_OK;
+}
+
+extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, uint32_t n, float* t, int32_t* tri_id) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, PTX_ERR_STATE, "ptx_trace_closest: ptx_upload_scene first");
+    if (n == 0) return PTX_OK;
+    if (!o || !d || !t || !tri_id) return fail(ctx, PTX_ERR_INVALID, "ptx_trace_closest: NULL array");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
+    int* d_tri = nullptr;
+    hipError_t e = hipMalloc(&d_o, (size_t)n * 12);
+    if (e == hipSuccess) e = hipMalloc(&d_d, (size_t)n * 12);
+    if (e == hipSuccess) e = hipMalloc(&d_t, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_tri, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_o, o, (size_t)n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, d, (size_t)n * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const uint32_t blocks = (n + 63) / 64;
+        if (ctx->opt_traversal) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(64), 0, ctx->stream, ctx->S, d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+        else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(64), 0, ctx->stream, ctx->S, d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(tri_id, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_tri);
+    if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_trace_closest: ") + hipGetErrorString(e));
+    return PTX_OK;
+}
+
+extern "C" int ptx_primary_hits(ptx_ctx* ctx, int32_t* tri_id, float* t) {
+    if (!ctx || !tri_id || !t) return PTX_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_primary(ctx, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    HIP_TRY(ctx, hipMemcpy(tri_id, ctx->d_prim_tri, npix * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(t, ctx->d_prim_t, npix * 4, hipMemcpyDeviceToHost));
+    return PTX_OK;
+}
+
+extern "C" int ptx_primary_dirs(ptx_ctx* ctx, float* dirs) {
+    if (!ctx || !dirs) return PTX_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "scene and params must be set first");
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    float4* d_dirs = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_dirs, npix * sizeof(float4)));
+    int rc = ensure_primary(ctx, d_dirs);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    std::vector<float4> h(npix);
+    if (rc == PTX_OK && e == hipSuccess) e = hipMemcpy(h.data(), d_dirs, npix * sizeof(float4), hipMemcpyDeviceToHost);
+    (void)hipFree(d_dirs);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_primary_dirs: ") + hipGetErrorString(e));
+    for (size_t i = 0; i < npix; i++) { dirs[3 * i] = h[i].x; dirs[3 * i + 1] = h[i].y; dirs[3 * i + 2] = h[i].z; }
+    return PTX_OK;
+}
+
+extern "C" int ptx_get_counters(ptx_ctx* ctx, ptx_counters* out) {
+    if (!ctx || !out) return PTX_ERR_INVALID;
+    int rc = ptx_synchronize(ctx);
+    if (rc) return rc;
+    unsigned long long h[CNT_NUM];
+    HIP_TRY(ctx, hipMemcpy(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    out->samples = h[CNT_SAMPLES]; out->rays = h[CNT_RAYS]; out->rays_traced = h[CNT_RAYS_TRACED];
+    out->node_visits = h[CNT_NODE_VISITS]; out->tri_tests = h[CNT_TRI_TESTS]; out->ray_hits = h[CNT_RAY_HITS];
+    out->light_attempts = h[CNT_LIGHT_ATTEMPTS]; out->pixel_frames = h[CNT_PIXEL_FRAMES];
+    out->kernel_launches = ctx->kernel_launches;
+    out->kernel_ms = ctx->kernel_ms;
+    return PTX_OK;
+}
+
+extern "C" int ptx_reset_counters(ptx_ctx* ctx) {
+    if (!ctx) return PTX_ERR_INVALID;
+    int rc = ptx_synchronize(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long)));
+    ctx->kernel_ms = 0.0;
+    ctx->kernel_launches = 0;
+    return PTX_OK;
+}
+
+extern "C" int ptx_accum_export_device(ptx_ctx* ctx, void* d_dst) {
+    if (!ctx || !d_dst) return PTX_ERR_INVALID;
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, ctx->d_accum, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    return PTX_OK;
+}
+
+extern "C" int ptx_accum_import_device(ptx_ctx* ctx, const void* d_src, uint32_t frames_done) {
+    if (!ctx || !d_src) return PTX_ERR_INVALID;
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, d_src, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->frames_done = frames_done;
+    return PTX_OK;
+}
