@@ -154,6 +154,16 @@ def render_frame(s, p, timestamp, y0=0, y1=None, nthreads=0, out=None):
     return rgb, cnt.as_dict()
 
 
+def render_rows(s, p, timestamp, y0, y1, y_step, nthreads=0):
+    """Rows y0, y0+y_step, ... only (other rows stay zero). Returns (rgb, counters)."""
+    rgb = np.zeros((p.height, p.width, 3), dtype=np.float32)
+    cnt = OrcCounters()
+    cs, cp = c_scene(s), c_params(p)
+    lib().orc_render_rows(C.byref(cs), C.byref(cp), C.c_int32(int(timestamp)), C.c_uint32(y0), C.c_uint32(y1),
+                          C.c_uint32(y_step), _fp(rgb), C.byref(cnt), C.c_int(nthreads))
+    return rgb, cnt.as_dict()
+
+
 def render_frames(s, p, timestamps, nthreads=0):
     """Sum over frames of the per-frame clamped mean, added in frame order in f32 (the product's accumulation)."""
     acc = np.zeros((p.height, p.width, 3), dtype=np.float32)

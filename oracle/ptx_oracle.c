@@ -344,8 +344,14 @@ int orc_max_threads(void) {
 }
 
 void orc_render_frame(const orc_scene *s, const orc_params *p, int32_t timestamp, uint32_t y0,
-                      uint32_t y1, float *rgb_out, orc_counters *c, int nthreads) { /* glsl:493-529 */
+                      uint32_t y1, float *rgb_out, orc_counters *c, int nthreads) {
+    orc_render_rows(s, p, timestamp, y0, y1, 1, rgb_out, c, nthreads);
+}
+
+void orc_render_rows(const orc_scene *s, const orc_params *p, int32_t timestamp, uint32_t y0, uint32_t y1,
+                     uint32_t y_step, float *rgb_out, orc_counters *c, int nthreads) { /* glsl:493-529 */
     if (y1 > p->height) y1 = p->height;
+    if (y_step == 0) y_step = 1;
     orc_counters total;
     memset(&total, 0, sizeof total);
     v3 src = ld3(p->cam_src);
@@ -359,7 +365,7 @@ void orc_render_frame(const orc_scene *s, const orc_params *p, int32_t timestamp
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
-        for (int64_t y = (int64_t)y0; y < (int64_t)y1; y++) {
+        for (int64_t y = (int64_t)y0; y < (int64_t)y1; y += (int64_t)y_step) {
             for (uint32_t x = 0; x < p->width; x++) {
                 float d[3];
                 uint32_t seed[2];

@@ -27,8 +27,8 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return mk(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
 }
-__device__ __forceinline__ float length(V3 a) { return __fsqrt_rn(dot(a, a)); }
-__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / __fsqrt_rn(dot(a, a))); }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 __device__ __forceinline__ bool any_ne(V3 a, V3 b) { return a.x != b.x || a.y != b.y || a.z != b.z; }
 
@@ -72,12 +72,12 @@ __device__ __forceinline__ void sincos_2pi(float theta, float& s, float& c) {
 // glsl:315-337
 __device__ __forceinline__ V3 sample_hemisphere(float r0, float r1, V3 n) {
     float theta = (2.0f * PTX_M_PI) * r0;
-    float r = __fsqrt_rn(r1);
+    float r = sqrtf(r1);
     float sn, cs;
     sincos_2pi(theta, sn, cs);
     float x = r * cs;
     float y = r * sn;
-    float z = __fsqrt_rn(1.0f - r * r);
+    float z = sqrtf(1.0f - r * r);
     V3 major = fabsf(n.x) < 0.57735026919f ? mk(1.f, 0.f, 0.f) : (fabsf(n.y) < 0.57735026919f ? mk(0.f, 1.f, 0.f) : mk(0.f, 0.f, 1.f));
     V3 u = normalize(cross(n, major));
     V3 v = cross(n, u);
