@@ -1,0 +1,50 @@
+"""world_size-2 gloo test of the multi-GPU partition (frames round-robin + one all-reduce) -- CPU only.
+The CPU oracle stands in for the per-rank renderer; what is under test is frames_for_rank + allreduce_sum."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ptx_import
+    m = ptx_import.load()
+    from oracle import orc
+    s = m.load_scene("my_cornell_6")
+    p = m.config_params("my_cornell_6", 16, 16, 2, 3)
+    ts = m.scene.timestamps(n_frames)
+    mine = m.frames_for_rank(n_frames, rank, world)
+    acc, _ = orc.render_frames(s, p, ts[mine], nthreads=1)
+    t = torch.from_numpy(acc.copy())
+    m.allreduce_sum(t)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "sum.npy"), t.numpy())
+    dist.destroy_process_group()
+
+
+def test_frames_for_rank_partition(ptx):
+    for n in (0, 1, 5, 64):
+        for world in (1, 2, 3, 8):
+            parts = [ptx.frames_for_rank(n, r, world) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(q) for q in parts) - min(len(q) for q in parts) <= 1
+
+
+def test_two_rank_frame_split_equals_single_process(ptx, orc, tmp_path):
+    n_frames, world = 5, 2
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "sum.npy")
+    s = ptx.load_scene("my_cornell_6")
+    p = ptx.config_params("my_cornell_6", 16, 16, 2, 3)
+    want, _ = orc.render_frames(s, p, ptx.scene.timestamps(n_frames), nthreads=1)
+    # same frames, different float-add association: a few ulp of the sum (values in [0, n_frames])
+    assert np.abs(got - want).max() <= 4 * np.finfo(np.float32).eps * n_frames

@@ -1,0 +1,240 @@
+"""Parity of the HIP path (through the C ABI, libptx_hip.so) against the CPU oracle -- needs an MI355X.
+
+Bar: bit-exact.  Triangle ids are integers; the float results (t, directions, radiance sums) are required to be
+bit-identical too because both sides implement the same strict-binary32 arithmetic contract.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["cornell", "my_cornell_6", "bedroom2_v5", "teapot", "pixar_room"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def setup(ctx, ptx, name, w, h, spp=4, bounces=4, **opts):
+    s = ptx.load_scene(name)
+    p = ptx.config_params(name, w, h, spp, bounces)
+    ctx.upload_scene(s)
+    ctx.set_params(p)
+    for k, v in dict(traversal=1, memo=1, count=0, frame_batch=0, **opts).items():
+        ctx.set_option(k, v)
+    ctx.reset_accum()
+    ctx.reset_counters()
+    return s, p
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("size", [(96, 54), (40, 64), (33, 33)])
+@pytest.mark.parametrize("traversal", [0, 1])
+def test_primary_dirs_and_hits_bit_exact(gpu_ctx, ptx, orc, name, size, traversal):
+    s, p = setup(gpu_ctx, ptx, name, *size, traversal=traversal)
+    assert (bits(gpu_ctx.primary_dirs()) == bits(orc.primary_dirs(p))).all()
+    t_g, tri_g = gpu_ctx.primary_hits()
+    t_o, tri_o, _ = orc.primary_hits(s, p)
+    assert (tri_g == tri_o).all()
+    assert (bits(t_g) == bits(t_o)).all()
+
+
+def random_rays(s, n, seed):
+    rng = np.random.default_rng(seed)
+    lo, hi = s.node_min[:3], s.node_max[:3]
+    o = (lo + (hi - lo) * rng.random((n, 3))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # axis-parallel rays (inf slabs), rays starting ON triangles (self-hit epsilon), rays from outside the scene
+    d[: n // 10] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n // 10)] * rng.choice([-1, 1], (n // 10, 1)).astype(np.float32)
+    tri = rng.integers(0, s.T, n // 10)
+    c = s.coords.reshape(-1, 3, 3)[tri]
+    w = rng.dirichlet([1, 1, 1], n // 10).astype(np.float32)
+    o[n // 10: n // 10 + n // 10] = (c * w[:, :, None]).sum(axis=1)
+    o[-n // 10:] = (lo - (hi - lo) * rng.random((n // 10, 3))).astype(np.float32)
+    return o, d
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("traversal", [0, 1])
+def test_trace_closest_bit_exact(gpu_ctx, ptx, orc, name, traversal):
+    s, _ = setup(gpu_ctx, ptx, name, 8, 8, traversal=traversal)
+    o, d = random_rays(s, 20000, 7)
+    t_g, tri_g = gpu_ctx.trace_closest(o, d)
+    t_o, tri_o, c = orc.trace_closest(s, o, d)
+    assert (tri_g == tri_o).all() and (bits(t_g) == bits(t_o)).all()
+    assert (tri_o >= 0).sum() > 1000                                    # the test really hits geometry
+    k = gpu_ctx.counters()
+    assert k["rays"] == 20000 and k["ray_hits"] == c["ray_hits"]
+    if traversal == 0:                                                  # literal traversal does the reference's work exactly
+        assert k["node_visits"] == c["node_visits"] and k["tri_tests"] == c["tri_tests"]
+    else:
+        assert k["node_visits"] <= c["node_visits"] and k["tri_tests"] <= c["tri_tests"]
+
+
+def test_trace_closest_empty_and_single(gpu_ctx, ptx, orc):
+    s, _ = setup(gpu_ctx, ptx, "my_cornell_6", 8, 8)
+    t, tri = gpu_ctx.trace_closest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert t.size == 0 and tri.size == 0
+    t, tri = gpu_ctx.trace_closest([[100, 100, 100]], [[1, 0, 0]])
+    assert tri[0] == -1 and t[0] == np.float32(1e38)
+
+
+@pytest.mark.parametrize("name,size,spp,bounces", [("cornell", (48, 48), 4, 4), ("my_cornell_6", (64, 64), 4, 5), ("bedroom2_v5", (64, 36), 3, 4),
+                                                   ("teapot", (64, 36), 3, 4), ("pixar_room", (96, 54), 4, 8), ("pixar_room", (27, 45), 2, 12)])
+@pytest.mark.parametrize("traversal,memo", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_frames_bit_exact_and_counters(gpu_ctx, ptx, orc, name, size, spp, bounces, traversal, memo):
+    s, p = setup(gpu_ctx, ptx, name, *size, spp=spp, bounces=bounces, traversal=traversal, memo=memo, count=1)
+    ts = ptx.scene.timestamps(3)
+    gpu_ctx.render_frames(ts)
+    got = gpu_ctx.read_sum()
+    want, oc = orc.render_frames(s, p, ts)
+    assert (bits(got) == bits(want)).all()
+    assert want.max() > 0                                               # not a black image
+    k = gpu_ctx.counters()
+    for key in ("samples", "rays", "ray_hits", "light_attempts"):
+        assert k[key] == oc[key], key
+    assert k["pixel_frames"] == 3 * p.width * p.height
+    if traversal == 0 and memo == 0:
+        assert k["node_visits"] == oc["node_visits"] and k["tri_tests"] == oc["tri_tests"] and k["rays_traced"] == oc["rays"]
+    if memo == 1:
+        assert k["rays_traced"] < k["rays"]
+
+
+def test_golden_frame_fixture(gpu_ctx, ptx):
+    """Committed golden vectors (tests/golden/frames.npz, written by tests/golden/make_golden_frames.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "frames.npz"))
+    for key in [k for k in g.files if k.endswith("_sum")]:
+        name, w, h, spp, bounces, nfr = key[:-4].rsplit("-", 5)
+        s, p = setup(gpu_ctx, ptx, name, int(w), int(h), spp=int(spp), bounces=int(bounces))
+        gpu_ctx.render_frames(ptx.scene.timestamps(int(nfr)))
+        assert (bits(gpu_ctx.read_sum()) == bits(g[key])).all(), key
+        _, tri = gpu_ctx.primary_hits()
+        assert (tri == g[key[:-4] + "_tri"]).all(), key
+
+
+def test_edge_cases(gpu_ctx, ptx, orc):
+    # L = 0: black image, no light attempts (cornell through the faithful loader)
+    s, p = setup(gpu_ctx, ptx, "cornell_faithful", 24, 24)
+    gpu_ctx.render_frames([1000, 1001])
+    assert not gpu_ctx.read_sum().any() and gpu_ctx.counters()["light_attempts"] == 0
+    # 1x1 image, 1 sample, 1 bounce; odd timestamps (negative, > 16 bits: only the low 16 bits seed, glsl:520)
+    for (w, h, spp, b, ts) in [(1, 1, 1, 1, [0]), (7, 5, 1, 1, [-1]), (9, 13, 2, 2, [0x12345, 70000]), (16, 16, 5, 1, [65535])]:
+        s, p = setup(gpu_ctx, ptx, "my_cornell_6", w, h, spp=spp, bounces=b)
+        gpu_ctx.render_frames(ts)
+        want, _ = orc.render_frames(s, p, ts)
+        assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (w, h, spp, b, ts)
+    # max_path_length = 0: the bounce loop never runs (glsl:408) -> black, but samples are counted
+    s, p = setup(gpu_ctx, ptx, "my_cornell_6", 8, 8, spp=3, bounces=0)
+    gpu_ctx.render_frames([1000])
+    assert not gpu_ctx.read_sum().any() and gpu_ctx.counters()["samples"] == 8 * 8 * 3
+    # n_frames = 0 is a no-op
+    gpu_ctx.render_frames([])
+    assert gpu_ctx.frames_done == 1
+
+
+def test_accumulation_semantics(gpu_ctx, ptx, orc):
+    s, p = setup(gpu_ctx, ptx, "my_cornell_6", 40, 24, spp=2, bounces=3)
+    ts = ptx.scene.timestamps(7)
+    want, _ = orc.render_frames(s, p, ts)
+    for batch in (1, 3, 0):                                             # frame-batch size never changes the sum
+        gpu_ctx.set_option("frame_batch", batch)
+        gpu_ctx.reset_accum()
+        gpu_ctx.render_frames(ts)
+        assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), batch
+    gpu_ctx.reset_accum()                                               # two calls == one call
+    gpu_ctx.render_frames(ts[:4]); gpu_ctx.render_frames(ts[4:], first_frame_number=4)
+    assert gpu_ctx.frames_done == 7
+    assert (bits(gpu_ctx.read_sum()) == bits(want)).all()
+    lin = gpu_ctx.read_linear()
+    assert (bits(lin) == bits((want / np.float32(7)).astype(np.float32))).all()
+    # display pass: pow(c, 1/2.2), unorm8, flip (fragmentShaderOutput.glsl:35, main.js:464-473); pow is not exactly
+    # rounded on either side -> +-1 code value
+    px = gpu_ctx.read_rgba8(apply_gamma=True, flip_y=True)
+    ref = np.floor(np.clip(lin.astype(np.float64), 0, 1) ** (1 / 2.2) * 255 + 0.5)[::-1]
+    assert np.abs(px[..., :3].astype(np.int32) - ref.astype(np.int32)).max() <= 1 and (px[..., 3] == 255).all()
+    raw = gpu_ctx.read_rgba8(apply_gamma=False, flip_y=False)
+    assert (raw[..., :3] == np.floor(np.clip(lin, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint8)).all()
+    # reference-compat check: with ONE frame the RGBA8 image equals the reference's render target (blend factor 1)
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1])
+    one, _ = orc.render_frame(s, p, int(ts[0]))
+    assert (gpu_ctx.read_rgba8(False, False) == orc.blend_rgba8(p, one, None, 0)).all()
+
+
+def test_device_export_import_for_allreduce(gpu_ctx, ptx):
+    import torch
+    s, p = setup(gpu_ctx, ptx, "my_cornell_6", 32, 16, spp=2, bounces=2)
+    gpu_ctx.render_frames([1000, 1001])
+    base = gpu_ctx.read_sum()
+    t = torch.zeros(16, 32, 4, dtype=torch.float32, device="cuda:0")
+    gpu_ctx.accum_export_device(t.data_ptr())
+    torch.cuda.synchronize()
+    assert (bits(t[..., :3].cpu().numpy()) == bits(base)).all()
+    t *= 2
+    torch.cuda.synchronize()
+    gpu_ctx.accum_import_device(t.data_ptr(), 4)
+    assert gpu_ctx.frames_done == 4 and (bits(gpu_ctx.read_sum()) == bits(base * 2)).all()
+
+
+def test_error_behaviour(ptx):
+    b = ptx.binding
+    lib = ptx.load_library()
+    assert lib.ptx_create((C.c_int * 2)(0, 0), 2) is None and b"one" in lib.ptx_last_error(None)
+    with pytest.raises(ptx.PtxError):
+        ptx.Context(99)
+    ctx = ptx.Context(0)
+    with pytest.raises(ptx.PtxError) as e:
+        ctx.render_frames([1000])
+    assert e.value.status == b.PTX_ERR_STATE
+    s = ptx.load_scene("my_cornell_6")
+    import copy
+    for field, idx, val in [("node_miss", 5, 5), ("node_miss", 5, 2), ("node_miss", 0, s.N), ("node_first", 3, s.T), ("node_count", 3, 200),
+                            ("inorder_tri", 0, s.T), ("inorder_tri", 1, -1), ("light_tri", 0, s.T)]:
+        bad = copy.deepcopy(s)
+        getattr(bad, field)[idx] = val
+        with pytest.raises(ptx.PtxError) as e:
+            ctx.upload_scene(bad)
+        assert e.value.status == b.PTX_ERR_INVALID, (field, idx, val)
+    ctx.upload_scene(s)
+    with pytest.raises(ptx.PtxError):
+        ctx.set_option("nonsense", 1)
+    p = ptx.config_params("my_cornell_6", 8, 8)
+    p.sample_count = 0
+    with pytest.raises(ptx.PtxError):
+        ctx.set_params(p)
+    ctx.close()
+
+
+# ---------------------------------------------------------------- BASELINE.json's full sizes: properties + oracle row samples
+
+@pytest.mark.parametrize("cfg", ["C2", "C4", "headline"])
+def test_full_size_properties(gpu_ctx, ptx, orc, cfg):
+    c = ptx.CONFIGS[cfg]
+    s, p = setup(gpu_ctx, ptx, c["scene"], c["width"], c["height"], spp=c["sample_count"], bounces=c["max_path_length"])
+    ts = ptx.scene.timestamps(2)
+    # (1) primary hits: literal == pruned over the whole image, and == oracle on sampled rows
+    gpu_ctx.set_option("traversal", 0); t0, tri0 = gpu_ctx.primary_hits()
+    gpu_ctx.set_option("traversal", 1); t1, tri1 = gpu_ctx.primary_hits()
+    assert (tri0 == tri1).all() and (bits(t0) == bits(t1)).all()
+    # (2) one frame: pruned+memo == literal+no-memo (the reference's every-ray algorithm), whole image, bit for bit
+    gpu_ctx.set_option("traversal", 0); gpu_ctx.set_option("memo", 0)
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); lit = gpu_ctx.read_sum()
+    gpu_ctx.set_option("traversal", 1); gpu_ctx.set_option("memo", 1)
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); fa = gpu_ctx.read_sum()
+    assert (bits(lit) == bits(fa)).all()
+    # (3) linearity of the accumulation: frames {a,b} together == a + b
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[1:]); fb = gpu_ctx.read_sum()
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts); both = gpu_ctx.read_sum()
+    assert (bits(both) == bits((fa + fb).astype(np.float32))).all()
+    assert 0 <= both.min() and both.max() <= 2.0                         # each frame is clamped to [0,1] (glsl:527)
+    # (4) the oracle on an evenly spread row sample of the same full-size frame
+    step = c["height"] // 6
+    rows, _ = orc.render_rows(s, p, int(ts[0]), 3, c["height"], step)
+    ys = list(range(3, c["height"], step))
+    assert (bits(fa[ys]) == bits(rows[ys])).all()
+    _, tri_o, _ = orc.primary_hits(s, ptx.config_params(c["scene"], c["width"], c["height"])) if cfg == "C2" else (None, None, None)
+    if tri_o is not None:
+        assert (tri_o == tri1).all()
