@@ -34,9 +34,9 @@ def cpu_baseline(m, scene, params, seconds_target=15.0):
     """Times the CPU oracle (kind 'port') on an evenly spread row sample of frame 0 of the same workload."""
     from oracle import orc
     threads = min(orc.max_threads(), 16)
-    # calibrate on 1/540 of the rows, then size the sample for ~seconds_target
+    # calibrate on ~2 rows per thread, then size the sample for ~seconds_target
     t0 = time.time()
-    _, c = orc.render_rows(scene, params, 1000, 0, params.height, 540, nthreads=threads)
+    _, c = orc.render_rows(scene, params, 1000, 0, params.height, max(1, params.height // (2 * threads)), nthreads=threads)
     dt = time.time() - t0
     rate = c["samples"] / max(dt, 1e-6)
     rows = int(max(2, min(params.height, rate * seconds_target / (params.width * params.sample_count))))

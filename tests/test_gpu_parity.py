@@ -22,7 +22,7 @@ def setup(ctx, ptx, name, w, h, spp=4, bounces=4, **opts):
     p = ptx.config_params(name, w, h, spp, bounces)
     ctx.upload_scene(s)
     ctx.set_params(p)
-    for k, v in dict(traversal=1, memo=1, count=0, frame_batch=0, **opts).items():
+    for k, v in {**dict(traversal=1, memo=1, count=0, frame_batch=0), **opts}.items():
         ctx.set_option(k, v)
     ctx.reset_accum()
     ctx.reset_counters()
@@ -191,7 +191,8 @@ def test_error_behaviour(ptx):
     assert e.value.status == b.PTX_ERR_STATE
     s = ptx.load_scene("my_cornell_6")
     import copy
-    for field, idx, val in [("node_miss", 5, 5), ("node_miss", 5, 2), ("node_miss", 0, s.N), ("node_first", 3, s.T), ("node_count", 3, 200),
+    leaf = int(np.nonzero(s.node_first != -2)[0][0])
+    for field, idx, val in [("node_miss", 5, 5), ("node_miss", 5, 2), ("node_miss", 0, s.N), ("node_first", leaf, s.T), ("node_count", leaf, 200),
                             ("inorder_tri", 0, s.T), ("inorder_tri", 1, -1), ("light_tri", 0, s.T)]:
         bad = copy.deepcopy(s)
         getattr(bad, field)[idx] = val
