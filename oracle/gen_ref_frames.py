@@ -1,0 +1,82 @@
+"""Generates tests/golden/ref_frames/*.npz: frames rendered by the REFERENCE shader itself, verbatim, on the
+SwiftShader WebGL2 of kaleido's headless Chromium (build container only; TEST INFRASTRUCTURE).
+
+    python oracle/gen_ref_frames.py [case ...]
+
+The shader text is read from /root/reference/shaders at run time and sent in the request; it is never written
+into this repository.  Each fixture holds the RGBA8 frames (bottom-up rows, as gl.readPixels returns them), the
+uniform block, the scene fixture name and the draw times.  frameNumber is 0 for every frame, so each frame is the
+un-blended per-frame image clamp(mean of sample_count paths) quantised by the RGBA8 target.
+"""
+import base64
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ptx_import  # noqa: E402
+
+REF = "/root/reference/shaders"
+OUT = os.path.join(ROOT, "tests", "golden", "ref_frames")
+
+# name: (scene fixture, W, H, sample_count, max_path_length, timestamps)
+CASES = {
+    "my_cornell_6_b1": ("my_cornell_6", 48, 48, 8, 1, [1000, 1001]),
+    "my_cornell_6_b3": ("my_cornell_6", 48, 48, 8, 3, [1000, 1001]),
+    "cornell_b1": ("cornell", 40, 40, 8, 1, [1000]),
+    "cornell_c1": ("cornell", 256, 256, 16, 4, [1000]),          # BASELINE.json config 1 exactly
+    "bedroom2_v5_b1": ("bedroom2_v5", 48, 27, 4, 1, [1000]),
+    "pixar_room_b1": ("pixar_room", 48, 27, 4, 1, [1000]),
+    "pixar_room_b8": ("pixar_room", 96, 54, 16, 8, [1000]),      # reduced headline (BASELINE.md plan 1)
+    "my_cornell_6_tall_b1": ("my_cornell_6", 24, 40, 4, 1, [1000]),
+}
+
+
+def kaleido_exe():
+    import kaleido
+    return os.path.join(os.path.dirname(kaleido.__file__), "executable", "kaleido")
+
+
+def run_case(name):
+    m = ptx_import.load()
+    scene_name, w, h, spp, bounces, ts = CASES[name]
+    s = m.load_scene(scene_name)
+    cam = m.load_camera(scene_name)
+    f32 = lambda v: [float(np.float32(x)) for x in v]  # noqa: E731
+    payload = {
+        "width": w, "height": h, "sample_count": spp, "max_path_length": bounces, "timestamps": ts,
+        "cam_src": f32(cam["cam_src"]), "cam_dir": f32(cam["cam_dir"]), "cam_up": f32(cam["cam_up"]),
+        "cam_right": f32(cam["cam_right"]), "cam_left_bottom": f32(cam["cam_left_bottom"]),
+        "vertexShader": open(os.path.join(REF, "vertexShader.glsl")).read(),
+        "fragmentShader": open(os.path.join(REF, "fragmentShaderPathTracing.glsl")).read(),
+        "scene": {"T": s.T, "N": s.N, "L": s.L, **{k: getattr(s, k).tolist() for k in
+                  ("coords", "normals", "colors", "emissions", "light_tri", "node_min", "node_max", "node_miss", "node_first", "node_count", "inorder_tri")}},
+    }
+    req = {"data": {"data": [{"type": "scatter", "customdata": [payload]}], "layout": {}}, "format": "json", "width": 16, "height": 16, "scale": 1}
+    cmd = [kaleido_exe(), "plotly", "--plotlyjs=" + os.path.join(ROOT, "oracle", "webgl_harness.js"), "--no-sandbox", "--disable-gpu",
+           "--single-process", "--disable-breakpad"]
+    t0 = time.time()
+    proc = subprocess.run(cmd, input=(json.dumps(req) + "\n").encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=7200)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    reply = json.loads(lines[-1])
+    res = reply.get("result")
+    if isinstance(res, str):
+        res = json.loads(res)
+    if not res or "error" in res:
+        raise RuntimeError(f"{name}: harness failed: {reply} / {proc.stderr.decode(errors='replace')[-500:]}")
+    frames = np.stack([np.frombuffer(base64.b64decode(b), dtype=np.uint8).reshape(h, w, 4) for b in res["frames"]])
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), frames=frames, scene=scene_name, width=w, height=h, sample_count=spp,
+                        max_path_length=bounces, timestamps=np.asarray(ts, dtype=np.int32), draw_ms=np.asarray(res["ms"]),
+                        renderer=json.dumps(res["info"]), host_cores=os.cpu_count())
+    print(name, res["info"], "draw ms", [round(x) for x in res["ms"]], "wall", round(time.time() - t0, 1), "s", flush=True)
+
+
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or list(CASES)):
+        run_case(n)

@@ -1,0 +1,75 @@
+#!/usr/bin/env node
+'use strict';
+/*
+ * main.js -- Node CLI counterpart of /root/reference/main.js (the browser page's top-level module):
+ * load a scene (main.js:78-90, 536-712), set up the camera preset (main.js:144-176), build + flatten the BVH
+ * (main.js:180-190), upload once, render `frames` frames of `sampleCount` paths per pixel (main.js:391-438),
+ * read the image back and save it (main.js:454-499).  What changed on purpose: source-level constants
+ * (main.js:1-15) became flags, the scene is uploaded once instead of every frame, there is no 32x32 tiling and no
+ * sleeping (both existed to dodge the browser's GPU watchdog), `timestamp` is a fixed list (1000 + frame) instead
+ * of performance.now() so renders are reproducible, and frames accumulate in f32 instead of RGBA8.
+ *
+ *   node main.js --scene file.gltf|file.obj|file.ptxs [--camera preset | --camera-json file] [--width 256]
+ *        [--height 256] [--frames 5] [--spp 5] [--bounces 5] [--out image.png|.ppm] [--dump-sum file.f32]
+ *        [--device 0] [--traversal 0|1] [--save-scene out.ptxs] [--light-material name]
+ */
+const fs = require('fs');
+const path = require('path');
+const { loadModel, buildSceneArrays } = require('./scene');
+const { readScene, writeScene } = require('./scenefile');
+const { cameraFromPreset } = require('./camera');
+const { PathTracer } = require('./ptx');
+const { writePNG, writePPM } = require('./png');
+
+function parseArgs(argv) {
+  const a = { camera: 'teapot', width: 256, height: 256, frames: 5, spp: 5, bounces: 5, device: 0 }; // defaults = main.js:7-10,164-167
+  for (let i = 2; i < argv.length; i++) {
+    const k = argv[i].replace(/^--/, '').replace(/-([a-z])/g, (m, c) => c.toUpperCase());
+    const v = argv[++i];
+    if (v === undefined) throw new Error('missing value for ' + argv[i - 1]);
+    a[k] = /^-?\d+$/.test(v) ? parseInt(v, 10) : v;
+  }
+  if (!a.scene) throw new Error('usage: node main.js --scene <file> [options]  (see the header of main.js)');
+  return a;
+}
+
+function main() {
+  const a = parseArgs(process.argv);
+  const t0 = Date.now();
+  let scene;
+  if (path.extname(a.scene) === '.ptxs') scene = readScene(a.scene);
+  else {
+    const opts = a.lightMaterial ? { materialOverrides: { [a.lightMaterial]: { emissive: [1, 1, 1] } } } : {};
+    scene = buildSceneArrays(loadModel(a.scene, opts).trianglesArray);
+  }
+  if (a.saveScene) writeScene(a.saveScene, scene);
+  console.log(`scene: T=${scene.T} N=${scene.N} L=${scene.L} (${Date.now() - t0} ms)`);
+
+  let camera;
+  if (a.cameraJson) {
+    const c = JSON.parse(fs.readFileSync(a.cameraJson, 'utf8')).camera;
+    camera = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_right, cameraLeftBottom: c.cam_left_bottom };
+  } else camera = cameraFromPreset(a.camera, a.width, a.height).getCamera();
+
+  const pt = new PathTracer(a.device);
+  pt.uploadScene(scene);
+  pt.setParams(a.width, a.height, camera, a.bounces, a.spp);
+  if (a.traversal !== undefined) pt.setOption('traversal', a.traversal);
+  const timestamps = [];
+  for (let f = 0; f < a.frames; f++) timestamps.push(1000 + f);
+  const t1 = Date.now();
+  pt.renderFrames(timestamps, 0);
+  const dt = (Date.now() - t1) / 1000;
+  const c = pt.counters();
+  console.log(`rendered ${a.frames} frames x ${a.spp} spp at ${a.width}x${a.height}, ${a.bounces} bounces in ${dt.toFixed(3)} s: ` +
+    `${(c.samples / dt / 1e6).toFixed(2)} Msamples/s, ${(c.rays / dt / 1e6).toFixed(1)} Mrays/s (kernel ${c.kernelMs.toFixed(1)} ms)`);
+  if (a.dumpSum) { const s = pt.readSum(); fs.writeFileSync(a.dumpSum, Buffer.from(s.buffer, s.byteOffset, s.byteLength)); }
+  if (a.out) {
+    const px = pt.readRgba8(true, true); // display gamma + vertical flip, like the output pass + main.js:464-473
+    (path.extname(a.out) === '.ppm' ? writePPM : writePNG)(a.out, px, a.width, a.height);
+    console.log('wrote ' + a.out);
+  }
+  pt.destroy();
+}
+
+try { main(); } catch (e) { console.error(String(e && e.message || e)); process.exit(1); }

@@ -1,0 +1,52 @@
+'use strict';
+/*
+ * PathTracer -- JS face of the C-ABI addon (csrc/ptx_napi.node over libptx_hip.so, include/ptx.h).
+ * It stands where the reference's main.js drives WebGL: uploadScene ~ the eleven uploadTexture() calls
+ * (main.js:272-282), setCamera/setParams ~ the uniform block (main.js:290-308), renderFrames ~ the tile loop of
+ * gl.drawArrays (main.js:330-355), read* ~ gl.readPixels (main.js:459).  No WebGL or CPU fallback: if the addon or
+ * a gfx950 device is missing, construction throws.
+ */
+const path = require('path');
+
+function loadAddon() {
+  const file = path.join(__dirname, '..', 'csrc', 'ptx_napi.node');
+  try { return require(file); } catch (e) {
+    throw new Error('ptx: cannot load ' + file + ' (build it with `make -C path-tracing_amd/csrc`): ' + e.message);
+  }
+}
+
+class PathTracer {
+  constructor(device) {
+    this.addon = loadAddon();
+    this.handle = this.addon.create(device || 0);
+    this.width = 0; this.height = 0;
+  }
+
+  /** scene: the typed arrays of host/scene.js buildSceneArrays() (or scenefile.readScene()). */
+  uploadScene(scene) { this.addon.uploadScene(this.handle, scene); }
+
+  /** camera: Camera.getCamera() record (classes/camera.js shape); values are rounded to f32 at the boundary. */
+  setParams(width, height, camera, maxPathLength, sampleCount) {
+    const v = (p) => (Array.isArray(p) ? p : [p.x, p.y, p.z]);
+    this.addon.setParams(this.handle, {
+      width, height, camSrc: v(camera.cameraSource), camUp: v(camera.cameraUp), camRight: v(camera.cameraRight),
+      camLeftBottom: v(camera.cameraLeftBottom), maxPathLength, sampleCount });
+    this.width = width; this.height = height;
+  }
+
+  setOption(key, value) { this.addon.setOption(this.handle, key, value); }
+  /** timestamps: one int per frame (uniform `timestamp`, main.js:300). Blocks until the frames are done. */
+  renderFrames(timestamps, firstFrameNumber) { this.addon.renderFrames(this.handle, Int32Array.from(timestamps), firstFrameNumber || 0); }
+  resetAccum() { this.addon.resetAccum(this.handle); }
+  get framesDone() { return this.addon.framesDone(this.handle); }
+  readLinear() { return this.addon.readLinear(this.handle, this.width, this.height); }
+  readSum() { return this.addon.readSum(this.handle, this.width, this.height); }
+  readRgba8(gamma, flipY) { return this.addon.readRgba8(this.handle, this.width, this.height, gamma !== false, flipY !== false); }
+  traceClosest(origins, directions) { return this.addon.traceClosest(this.handle, Float32Array.from(origins), Float32Array.from(directions)); }
+  primaryHits() { return this.addon.primaryHits(this.handle, this.width, this.height); }
+  counters() { return this.addon.counters(this.handle); }
+  resetCounters() { this.addon.resetCounters(this.handle); }
+  destroy() { if (this.handle) { this.addon.destroy(this.handle); this.handle = null; } }
+}
+
+module.exports = { PathTracer, loadAddon };
