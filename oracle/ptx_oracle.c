@@ -129,8 +129,85 @@ int orc_ray_tri(const float o[3], const float d[3], const float v0[3], const flo
     return ray_tri(ld3(o), ld3(d), ld3(v0), ld3(v1), ld3(v2), t);
 }
 
+/* ---- EXPERIMENT (not the reference algorithm): ordered, pruned, stack-based traversal of the SAME tree, used only
+ * to measure how much work an ordered traversal saves and whether its result equals the literal one.  Children of an
+ * internal node i are L = i+1 and R = miss[L]; the winner is the lexicographic minimum of (t, inorder slot). */
+static int g_traversal_mode = 0;   /* 0 literal, 1 literal + prune, 2 ordered + prune */
+static float g_prune_rel = 0.001f, g_prune_abs = 0.001f;
+void orc_set_traversal_mode(int mode, float rel, float abs_) { g_traversal_mode = mode; g_prune_rel = rel; g_prune_abs = abs_; }
+
+static inline int ray_box_t(v3 o, v3 inv, v3 bmin, v3 bmax, float *tn) {
+    v3 t1 = mul(sub(bmin, o), inv);
+    v3 t2 = mul(sub(bmax, o), inv);
+    float tNear = fmax_(fmax_(fmin_(t1.x, t2.x), fmin_(t1.y, t2.y)), fmin_(t1.z, t2.z));
+    float tFar = fmin_(fmin_(fmax_(t1.x, t2.x), fmax_(t1.y, t2.y)), fmax_(t1.z, t2.z));
+    *tn = tNear;
+    return (tNear <= tFar) && (tFar > 0.0f);
+}
+
+static int bvh_closest_experimental(const orc_scene *s, v3 o, v3 d, float *out_t, int32_t *out_tri, orc_counters *c) {
+    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float best = 1.0e38f, limit = 3.0e38f;
+    int32_t best_tri = -1, best_k = 0x7fffffff;
+    const int32_t N = (int32_t)s->N;
+    c->rays++;
+    if (g_traversal_mode == 1) {
+        int32_t i = 0;
+        while (i != -1 && i < N) {
+            float tn;
+            c->node_visits++;
+            if (ray_box_t(o, inv, ld3(s->node_min + 3 * i), ld3(s->node_max + 3 * i), &tn) && !(tn > limit)) {
+                int32_t first = s->node_first[i];
+                if (first != -2)
+                    for (int32_t k = first; k < first + s->node_count[i]; k++) {
+                        const float *p = s->coords + 9 * (size_t)s->inorder_tri[k];
+                        float t;
+                        c->tri_tests++;
+                        if (ray_tri(o, d, ld3(p), ld3(p + 3), ld3(p + 6), &t) && t < best) { best = t; best_tri = s->inorder_tri[k]; limit = best * (1.0f + g_prune_rel) + g_prune_abs; }
+                    }
+                i++;
+            } else i = s->node_miss[i];
+        }
+    } else {
+        int32_t stack[64]; float stn[64]; int sp = 0;
+        float tn;
+        c->node_visits++;
+        if (ray_box_t(o, inv, ld3(s->node_min), ld3(s->node_max), &tn)) { stack[sp] = 0; stn[sp++] = tn; }
+        while (sp > 0) {
+            int32_t i = stack[--sp];
+            if (stn[sp] > limit) continue;
+            int32_t first = s->node_first[i];
+            if (first != -2) {
+                for (int32_t k = first; k < first + s->node_count[i]; k++) {
+                    const float *p = s->coords + 9 * (size_t)s->inorder_tri[k];
+                    float t;
+                    c->tri_tests++;
+                    if (ray_tri(o, d, ld3(p), ld3(p + 3), ld3(p + 6), &t) && (t < best || (t == best && k < best_k))) {
+                        best = t; best_k = k; best_tri = s->inorder_tri[k]; limit = best * (1.0f + g_prune_rel) + g_prune_abs;
+                    }
+                }
+                continue;
+            }
+            int32_t L = i + 1, R = s->node_miss[L];
+            float tl, tr;
+            c->node_visits += 2;
+            int hl = ray_box_t(o, inv, ld3(s->node_min + 3 * L), ld3(s->node_max + 3 * L), &tl) && !(tl > limit);
+            int hr = ray_box_t(o, inv, ld3(s->node_min + 3 * R), ld3(s->node_max + 3 * R), &tr) && !(tr > limit);
+            if (hl && hr) {
+                if (tr < tl) { stack[sp] = L; stn[sp++] = tl; stack[sp] = R; stn[sp++] = tr; }
+                else { stack[sp] = R; stn[sp++] = tr; stack[sp] = L; stn[sp++] = tl; }
+            } else if (hl) { stack[sp] = L; stn[sp++] = tl; }
+            else if (hr) { stack[sp] = R; stn[sp++] = tr; }
+        }
+    }
+    *out_t = best; *out_tri = best_tri;
+    if (best < 1.0e38f) { c->ray_hits++; return 1; }
+    return 0;
+}
+
 /* glsl:207-249.  Returns hit flag; *tri = original triangle index of the closest hit. */
 static int bvh_closest(const orc_scene *s, v3 o, v3 d, float *out_t, int32_t *out_tri, orc_counters *c) {
+    if (g_traversal_mode) return bvh_closest_experimental(s, o, d, out_t, out_tri, c);
     float best = 1.0e38f;
     int32_t best_tri = -1;
     int32_t i = 0;

@@ -47,14 +47,17 @@ class CParams(C.Structure):
 
 class CCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "rays_traced", "node_visits", "tri_tests", "ray_hits",
-                                          "light_attempts", "pixel_frames", "kernel_launches")] + [("kernel_ms", C.c_double)]
+                                          "light_attempts", "pixel_frames", "kernel_launches")] + [("kernel_ms", C.c_double), ("diag", C.c_uint64 * 12)]
 
     def as_dict(self):
-        return {n: (float(getattr(self, n)) if n == "kernel_ms" else int(getattr(self, n))) for n, _ in self._fields_}
+        d = {n: (float(getattr(self, n)) if n == "kernel_ms" else int(getattr(self, n))) for n, _ in self._fields_ if n != "diag"}
+        d["diag"] = [int(x) for x in self.diag]
+        return d
 
 
 def lib_path():
-    return os.path.join(_HERE, "csrc", "libptx_hip.so")
+    # PTX_LIB_PATH: A/B builds of the same library (tools/perf.py); default = the in-tree build
+    return os.environ.get("PTX_LIB_PATH") or os.path.join(_HERE, "csrc", "libptx_hip.so")
 
 
 def load_library():

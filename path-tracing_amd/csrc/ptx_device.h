@@ -96,20 +96,21 @@ __device__ __forceinline__ bool slab_test(V3 o, V3 inv, V3 bmin, V3 bmax, float&
 }
 
 // glsl:150-173 with edge1 = v1 - v0 and edge2 = v2 - v0 precomputed (same f32 values).
+// Straight-line form: every quantity is computed unconditionally and the shader's four early returns are folded
+// into one predicate with the SAME comparisons (so NaN operands behave exactly as in the branchy original: a NaN u or
+// v is not rejected by 'u < 0 || u > 1').  In SIMT the early returns save nothing unless all 64 lanes take them, and
+// without them the three 16-B loads of a triangle record can all be issued up front.
 __device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float& t_out) {
     V3 h = cross(d, e2);
     float a = dot(e1, h);
-    if (a > -0.0001f && a < 0.0001f) return false;
     float f = 1.0f / a;
     V3 s = o - v0;
     float u = f * dot(s, h);
-    if (u < 0.0f || u > 1.0f) return false;
     V3 q = cross(s, e1);
     float v = f * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return false;
     float t = f * dot(e2, q);
-    if (t > 0.0001f) { t_out = t; return true; }
-    return false;
+    t_out = t;
+    return !(a > -0.0001f && a < 0.0001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0001f);
 }
 
 } // namespace ptx

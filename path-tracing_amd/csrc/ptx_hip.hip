@@ -4,7 +4,7 @@
 // -ffp-contract=off is part of the numerical contract (ptx_device.h): both the device code and the
 // host-side precomputation below (edges, light pdf, aspect) must round every operation separately.
 #include "../../include/ptx.h"
-#include "ptx_render.h"
+#include "ptx_wave.h"
 
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -126,7 +126,7 @@ struct ptx_ctx {
     size_t ts_cap = 0;
 
     // options
-    int opt_traversal = 1, opt_memo = 1, opt_count = 0, opt_pipeline = 0, opt_frame_batch = 0;
+    int opt_traversal = 1, opt_memo = 1, opt_count = 0, opt_pipeline = 1, opt_frame_batch = 0, opt_tasks_per_wave = 128;
 
     // counters + timing
     unsigned long long* d_counters = nullptr;
@@ -265,22 +265,22 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
 
-    std::vector<float4> nodeA(N), nodeB(N), v0(T), e1(T), e2(T), aN(T), aC(T), aE(T), light((size_t)L * 6);
+    std::vector<float4> nodes((size_t)N * 2), tris((size_t)T * 3), aN(T), aC(T), aE(T), light((size_t)L * 6);
     auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     for (uint32_t i = 0; i < N; i++) {
         const float* mn = sc->node_min + 3 * (size_t)i;
         const float* mx = sc->node_max + 3 * (size_t)i;
         const int32_t f = sc->node_first[i];
         const int32_t fc = (f == -2) ? -2 : (f | (sc->node_count[i] << 24));
-        nodeA[i] = make_float4(mn[0], mn[1], mn[2], bits(sc->node_miss[i]));
-        nodeB[i] = make_float4(mx[0], mx[1], mx[2], bits(fc));
+        nodes[2 * (size_t)i] = make_float4(mn[0], mn[1], mn[2], bits(sc->node_miss[i]));
+        nodes[2 * (size_t)i + 1] = make_float4(mx[0], mx[1], mx[2], bits(fc));
     }
     for (uint32_t k = 0; k < T; k++) {
         const int32_t tri = sc->inorder_tri[k];
         const float* p = sc->coords + 9 * (size_t)tri;
-        v0[k] = make_float4(p[0], p[1], p[2], bits(tri));
-        e1[k] = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.f); // glsl:151
-        e2[k] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.f); // glsl:152
+        tris[3 * (size_t)k] = make_float4(p[0], p[1], p[2], bits(tri));
+        tris[3 * (size_t)k + 1] = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.f); // glsl:151
+        tris[3 * (size_t)k + 2] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.f); // glsl:152
     }
     for (uint32_t t = 0; t < T; t++) {
         aN[t] = make_float4(sc->normals[3 * (size_t)t], sc->normals[3 * (size_t)t + 1], sc->normals[3 * (size_t)t + 2], 0.f);
@@ -305,8 +305,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     }
     DScene S = {};
     int rc;
-    if ((rc = upload(ctx, nodeA, &S.nodeA)) || (rc = upload(ctx, nodeB, &S.nodeB)) || (rc = upload(ctx, v0, &S.triV0)) ||
-        (rc = upload(ctx, e1, &S.triE1)) || (rc = upload(ctx, e2, &S.triE2)) || (rc = upload(ctx, aN, &S.attrN)) ||
+    if ((rc = upload(ctx, nodes, &S.nodes)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, aN, &S.attrN)) ||
         (rc = upload(ctx, aC, &S.attrC)) || (rc = upload(ctx, aE, &S.attrE)) || (rc = upload(ctx, light, &S.light))) {
         free_scene(ctx);
         return rc;
@@ -366,6 +365,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value == 0 || value == 1)) ctx->opt_pipeline = (int)value;
     else if (k == "frame_batch" && value >= 0 && value <= 4096) ctx->opt_frame_batch = (int)value;
+    else if (k == "tasks_per_wave" && value >= 64 && value <= (1 << 20)) ctx->opt_tasks_per_wave = (int)value;
     else return fail(ctx, PTX_ERR_INVALID, "ptx_set_option: unknown key or bad value: " + k);
     return PTX_OK;
 }
@@ -406,6 +406,16 @@ static void launch_render(ptx_ctx* ctx, uint32_t tiles, uint32_t nf) {
                        ctx->d_prim_tri, ctx->d_fb, ctx->d_counters);
 }
 
+template <bool PRUNE, bool MEMO, bool COUNT>
+static void launch_render_wave(ptx_ctx* ctx, uint32_t nf) {
+    const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
+    const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32: ptx_render_frames caps the batch
+    const uint32_t per_wave = (uint32_t)ctx->opt_tasks_per_wave;
+    const uint32_t blocks = (uint32_t)((total + per_wave - 1) / per_wave);
+    hipLaunchKernelGGL((k_render_wave<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_ts, ctx->d_prim_t,
+                       ctx->d_prim_tri, ctx->d_fb, nf, per_wave, ctx->d_counters);
+}
+
 extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
     if (!ctx) return PTX_ERR_INVALID;
     if (!timestamps && n_frames) return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames: timestamps is NULL");
@@ -420,6 +430,10 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
     // frames rendered concurrently: bounded by an 8 GiB frame-buffer budget (HBM is 288 GB) and 65535 grid.y
     size_t batch = ctx->opt_frame_batch > 0 ? (size_t)ctx->opt_frame_batch : std::min<size_t>(64, std::max<size_t>(1, (8ull << 30) / (npix * sizeof(float4))));
     batch = std::min<size_t>(batch, n_frames);
+    {   // pipeline 1 indexes (pixel, frame) tasks with 32 bits
+        const uint64_t padded = (uint64_t)((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8) * 64u;
+        batch = std::max<size_t>(1, std::min<size_t>(batch, (size_t)(0xF0000000ull / padded)));
+    }
     if (ctx->fb_frames < batch) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_fb) (void)hipFree(ctx->d_fb);
@@ -442,6 +456,18 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         const int sel = (ctx->opt_traversal ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
+        if (ctx->opt_pipeline == 1) {
+            switch (sel) {
+                case 0: launch_render_wave<false, false, false>(ctx, nf); break;
+                case 1: launch_render_wave<false, false, true>(ctx, nf); break;
+                case 2: launch_render_wave<false, true, false>(ctx, nf); break;
+                case 3: launch_render_wave<false, true, true>(ctx, nf); break;
+                case 4: launch_render_wave<true, false, false>(ctx, nf); break;
+                case 5: launch_render_wave<true, false, true>(ctx, nf); break;
+                case 6: launch_render_wave<true, true, false>(ctx, nf); break;
+                default: launch_render_wave<true, true, true>(ctx, nf); break;
+            }
+        } else
         switch (sel) {
             case 0: launch_render<false, false, false>(ctx, tiles, nf); break;
             case 1: launch_render<false, false, true>(ctx, tiles, nf); break;
@@ -588,6 +614,7 @@ extern "C" int ptx_get_counters(ptx_ctx* ctx, ptx_counters* out) {
     out->light_attempts = h[CNT_LIGHT_ATTEMPTS]; out->pixel_frames = h[CNT_PIXEL_FRAMES];
     out->kernel_launches = ctx->kernel_launches;
     out->kernel_ms = ctx->kernel_ms;
+    for (int k = 0; k < 12; k++) out->diag[k] = h[CNT_WALK_USEFUL + k];
     return PTX_OK;
 }
 

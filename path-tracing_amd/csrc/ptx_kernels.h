@@ -1,11 +1,11 @@
 // ptx_kernels.h -- device data layout + kernels of the progressive path tracer (gfx950).
 //
 // HBM layout (replaces the eleven RGB32F data textures of main.js:272-282; DESIGN.md "Data layout"):
-//   nodeA[N]  float4 { min.xyz, bits(miss link) }
-//   nodeB[N]  float4 { max.xyz, bits(leaf ? first | count << 24 : -2) }
-//   triV0[T]  float4 { v0.xyz, bits(original triangle index) }   -- indexed by INORDER SLOT k, so a
-//   triE1[T]  float4 { (v1 - v0).xyz, 0 }                             leaf's triangles are contiguous
-//   triE2[T]  float4 { (v2 - v0).xyz, 0 }
+//   nodes[2N] float4: [2i]   = { min.xyz, bits(miss link) }
+//                     [2i+1] = { max.xyz, bits(leaf ? first | count << 24 : -2) }      (one 32-B record per node)
+//   tris[3T]  float4: [3k]   = { v0.xyz, bits(original triangle index) }  -- indexed by INORDER SLOT k, so a
+//                     [3k+1] = { (v1 - v0).xyz, 0 }                           leaf's triangles are contiguous
+//                     [3k+2] = { (v2 - v0).xyz, 0 }                           (one 48-B record per triangle)
 //   attrN/attrC/attrE[T] float4 { normal | color | emission } by ORIGINAL triangle index
 //   light[L]  6 x float4 { v0, v1, v2, normal, emission, {1/(L*area),0,0,0} }
 // One node visit = 32 B, one triangle test = 48 B, attributes (48 B) only for the winning hit.
@@ -15,11 +15,8 @@
 namespace ptx {
 
 struct DScene {
-    const float4* nodeA;
-    const float4* nodeB;
-    const float4* triV0;
-    const float4* triE1;
-    const float4* triE2;
+    const float4* nodes;   // 2 float4 per node
+    const float4* tris;    // 3 float4 per inorder slot
     const float4* attrN;
     const float4* attrC;
     const float4* attrE;
@@ -35,11 +32,29 @@ struct DParams {
 };
 
 // device-side work counters (u64), one block of these per context
-enum { CNT_SAMPLES = 0, CNT_RAYS, CNT_RAYS_TRACED, CNT_NODE_VISITS, CNT_TRI_TESTS, CNT_RAY_HITS, CNT_LIGHT_ATTEMPTS, CNT_PIXEL_FRAMES, CNT_NUM };
+enum { CNT_SAMPLES = 0, CNT_RAYS, CNT_RAYS_TRACED, CNT_NODE_VISITS, CNT_TRI_TESTS, CNT_RAY_HITS, CNT_LIGHT_ATTEMPTS, CNT_PIXEL_FRAMES,
+       CNT_WALK_USEFUL, CNT_WALK_SLOTS, CNT_TRI_USEFUL, CNT_TRI_SLOTS, CNT_TRACE_USEFUL, CNT_TRACE_SLOTS, CNT_CYC_WALK, CNT_CYC_TRI, CNT_CYC_SHADE, CNT_IT_WALK, CNT_IT_TRI, CNT_IT_SHADE, CNT_NUM };
 
 struct LocalCnt {
     uint32_t samples, rays, rays_traced, node_visits, tri_tests, ray_hits, light_attempts;
+    // SIMT-efficiency diagnostics (COUNT builds only): lane-iterations that did work vs 64 x wave-iterations
+    uint32_t walk_useful, walk_slots, tri_useful, tri_slots, trace_useful, trace_slots;
 };
+
+// max of v over the ACTIVE lanes (usable inside divergent code: built from ballots only)
+__device__ __forceinline__ uint32_t active_max(uint32_t v) {
+    bool cand = true;
+    uint32_t mx = 0;
+#pragma unroll
+    for (int b = 15; b >= 0; b--) {
+        const bool bit = (v >> b) & 1u;
+        if (__ballot(cand && bit)) { mx |= 1u << b; cand = cand && bit; }
+    }
+    return mx;
+}
+__device__ __forceinline__ bool first_active_lane() {
+    return (__ffsll((unsigned long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63);
+}
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -60,6 +75,11 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
         atomicAdd(&g[CNT_LIGHT_ATTEMPTS], (unsigned long long)s6);
         atomicAdd(&g[CNT_PIXEL_FRAMES], (unsigned long long)s7);
     }
+    if (c.walk_slots | c.tri_slots | c.trace_slots | c.walk_useful | c.tri_useful | c.trace_useful) {
+        atomicAdd(&g[CNT_WALK_USEFUL], (unsigned long long)c.walk_useful); atomicAdd(&g[CNT_WALK_SLOTS], (unsigned long long)c.walk_slots);
+        atomicAdd(&g[CNT_TRI_USEFUL], (unsigned long long)c.tri_useful); atomicAdd(&g[CNT_TRI_SLOTS], (unsigned long long)c.tri_slots);
+        atomicAdd(&g[CNT_TRACE_USEFUL], (unsigned long long)c.trace_useful); atomicAdd(&g[CNT_TRACE_SLOTS], (unsigned long long)c.trace_slots);
+    }
 }
 
 // Margin of the best-t pruning (option "traversal" = 1): a node is skipped only when its slab entry
@@ -67,46 +87,86 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
 #define PTX_PRUNE_REL 0.001f
 #define PTX_PRUNE_ABS 0.001f
 
+// 32-bit byte offsets from a uniform base: lets the compiler use the SGPR-base + VGPR-offset addressing form.
+__device__ __forceinline__ float4 ld16(const float4* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// Leaves whose box was hit are collected PTX_LEAF_BATCH at a time before their triangles are tested, so the
+// lanes of a wave spend their time in two tight loops (node walk / triangle tests) instead of waiting on each
+// other's leaf loops inside the walk.  Legal because the threaded walk never depends on triangle results
+// (the reference does not prune); with PRUNE the cut uses the best t of earlier batches only (still conservative).
+#ifndef PTX_LEAF_BATCH
+#define PTX_LEAF_BATCH 4
+#endif
+
 // glsl:207-249: closest hit by the stackless threaded traversal (hit -> i+1, miss -> missLink).
-// Strict '<' keeps the first candidate in inorder position among equal t (the reference's tie rule).
-// PRUNE adds the conservative best-t cut; COUNT adds node/triangle counters.
+// Triangles are still tested in increasing inorder slot, and strict '<' keeps the first candidate among equal t
+// (the reference's tie rule).  PRUNE adds the conservative best-t cut; COUNT adds node/triangle counters.
 template <bool PRUNE, bool COUNT>
 __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& out_t, int& out_tri, LocalCnt& c) {
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float best = 1.0e38f;
     int best_tri = -1;
-    int i = 0;
-    const int N = S.N;
+    uint32_t i = 0;                       // -1 (end) wraps to 0xFFFFFFFF >= N
+    const uint32_t N = (uint32_t)S.N;
     float limit = 3.0e38f;
-    while (i != -1 && i < N) {
-        const float4 a = S.nodeA[i];
-        const float4 b = S.nodeB[i];
-        if (COUNT) c.node_visits++;
-        float tn;
-        bool hit = slab_test(o, inv, mk(a), mk(b), tn);
-        if (PRUNE) hit = hit && !(tn > limit);
-        if (hit) {
-            const int fc = __float_as_int(b.w);
-            if (fc != -2) {
-                const int first = fc & 0x00FFFFFF, cnt = (fc >> 24) & 0x7F;
-                for (int k = first; k < first + cnt; k++) {
-                    const float4 v0 = S.triV0[k];
-                    const float4 e1 = S.triE1[k];
-                    const float4 e2 = S.triE2[k];
-                    if (COUNT) c.tri_tests++;
-                    float t;
-                    if (tri_test(o, d, mk(v0), mk(e1), mk(e2), t) && t < best) {
-                        best = t;
-                        best_tri = __float_as_int(v0.w);
-                        if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
-                    }
+    do {
+        int pend[PTX_LEAF_BATCH];
+        int n = 0;
+        uint32_t it_walk = 0, it_tri = 0;
+        while (n < PTX_LEAF_BATCH && i < N) {
+            if (COUNT) it_walk++;
+            const float4 a = ld16(S.nodes, i << 5);
+            const float4 b = ld16(S.nodes, (i << 5) + 16);
+            if (COUNT) c.node_visits++;
+            float tn;
+            bool hit = slab_test(o, inv, mk(a), mk(b), tn);
+            if (PRUNE) hit = hit && !(tn > limit);
+            if (hit) {
+                const int fc = __float_as_int(b.w);
+                if (fc != -2) {
+#pragma unroll
+                    for (int q = 0; q < PTX_LEAF_BATCH; q++) if (q == n) pend[q] = fc;
+                    n++;
                 }
+                i++;
+            } else {
+                i = (uint32_t)__float_as_int(a.w);
             }
-            i++;
-        } else {
-            i = __float_as_int(a.w);
         }
-    }
+        int j = 0;
+        uint32_t k = 0, kend = 0;
+        for (;;) {
+            if (k == kend) {
+                if (j == n) break;
+                int fc = pend[0];
+#pragma unroll
+                for (int q = 1; q < PTX_LEAF_BATCH; q++) if (q == j) fc = pend[q];
+                j++;
+                k = (uint32_t)(fc & 0x00FFFFFF);
+                kend = k + (uint32_t)((fc >> 24) & 0x7F);
+                if (k == kend) continue;  // empty leaf
+            }
+            if (COUNT) it_tri++;
+            const float4 v0 = ld16(S.tris, k * 48u);
+            const float4 e1 = ld16(S.tris, k * 48u + 16u);
+            const float4 e2 = ld16(S.tris, k * 48u + 32u);
+            if (COUNT) c.tri_tests++;
+            float t;
+            if (tri_test(o, d, mk(v0), mk(e1), mk(e2), t) && t < best) {
+                best = t;
+                best_tri = __float_as_int(v0.w);
+                if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+            }
+            k++;
+        }
+        if (COUNT) {
+            const uint32_t mw = active_max(it_walk), mt = active_max(it_tri);
+            c.walk_useful += it_walk; c.tri_useful += it_tri;
+            if (first_active_lane()) { c.walk_slots += 64u * mw; c.tri_slots += 64u * mt; }
+        }
+    } while (i < N);
     out_t = best;
     out_tri = best_tri;
     return best < 1.0e38f;

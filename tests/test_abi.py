@@ -28,7 +28,7 @@ def test_struct_layouts_match_header(ptx):
     b = ptx.binding
     assert ctypes.sizeof(b.CParams) == 4 * 2 + 4 * 12 + 4 * 2
     assert ctypes.sizeof(b.CScene) == 16 + 8 * 11            # 3 x u32 (+4 pad) + 11 pointers
-    assert ctypes.sizeof(b.CCounters) == 8 * 10
+    assert ctypes.sizeof(b.CCounters) == 8 * 22
 
 
 def test_no_cpu_fallback_without_gpu(ptx):
