@@ -331,6 +331,7 @@ extern "C" int ptx_set_params(ptx_ctx* ctx, const ptx_params* p) {
     if (!p) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: params is NULL");
     if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height > (1ull << 28)) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: bad image size");
     if (p->sample_count < 1) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: sample_count must be >= 1");
+    if (p->max_path_length > 65535) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: max_path_length must be <= 65535");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const bool resize = !ctx->have_params || ctx->P.W != p->width || ctx->P.H != p->height;

@@ -33,7 +33,7 @@
 #define PTX_WAVE_WALK_STEPS 1     // node steps per WALK phase
 #endif
 #ifndef PTX_WAVE_LEAF_TRIS
-#define PTX_WAVE_LEAF_TRIS 3      // triangles of the current leaf tested per TRI phase
+#define PTX_WAVE_LEAF_TRIS 2      // triangles of the current leaf tested per TRI phase
 #endif
 
 namespace ptx {
@@ -41,9 +41,10 @@ namespace ptx {
 // ---- per-lane path state parked in LDS between SHADE phases (struct-of-arrays: word w of lane l at [w*64 + l],
 //      conflict-free).  Only the SHADE phase touches it; WALK/TRI keep just the ray and the traversal cursor in
 //      registers, which keeps the hot loop small (few loop-carried registers, higher occupancy).
-enum { PW_SX = 0, PW_SY, PW_SUM, PW_DPRIM = PW_SUM + 3, PW_PRIMT = PW_DPRIM + 3, PW_PRIMTRI, PW_S, PW_O, PW_D = PW_O + 3, PW_THR = PW_D + 3,
-       PW_RAD = PW_THR + 3, PW_N = PW_RAD + 3, PW_COL = PW_N + 3, PW_LP = PW_COL + 3, PW_LPDF = PW_LP + 3, PW_LI, PW_ATT, PW_BOUNCE, PW_STAGE,
-       PW_PIX, PW_FRAME, PW_C_SAMPLES, PW_C_RAYS, PW_C_TRACED, PW_C_HITS, PW_C_ATT, PW_C_PF, PW_WORDS };
+// o and d are the lane's ray registers; dprim / prim_t / prim_tri are recomputed / reloaded from the pixel index.
+enum { PW_SX = 0, PW_SY, PW_SUM, PW_S = PW_SUM + 3, PW_THR, PW_RAD = PW_THR + 3, PW_N = PW_RAD + 3, PW_COL = PW_N + 3, PW_LP = PW_COL + 3,
+       PW_LPDF = PW_LP + 3, PW_LI, PW_PACK /* attempts | stage << 8 | bounce << 16 */, PW_PIX, PW_FRAME,
+       PW_C_SAMPLES, PW_C_RAYS, PW_C_TRACED, PW_C_HITS, PW_C_ATT, PW_C_PF, PW_WORDS };
 
 struct LdsLane {
     float* base;   // &lds[lane]
@@ -58,17 +59,36 @@ struct LdsLane {
 // Path accessors backed by the lane's LDS words (ptx_render.h: PTX_PATH_FIELDS)
 struct PathLds {
     LdsLane L;
+    V3& ro; V3& rd;                       // the ray lives in registers (the traversal needs it every step)
+    const DParams& P;
+    const float* prim_t_; const int* prim_tri_;
 #define X3(f, W) __device__ __forceinline__ V3 f() const { return L.ld3(W); } __device__ __forceinline__ void set_##f(V3 v) const { L.st3(W, v); }
 #define XF(f, W) __device__ __forceinline__ float f() const { return L.ld(W); } __device__ __forceinline__ void set_##f(float v) const { L.st(W, v); }
 #define XI(f, W) __device__ __forceinline__ int f() const { return L.ldi(W); } __device__ __forceinline__ void set_##f(int v) const { L.sti(W, v); }
 #define XU(f, W) __device__ __forceinline__ uint32_t f() const { return (uint32_t)L.ldi(W); } __device__ __forceinline__ void set_##f(uint32_t v) const { L.sti(W, (int)v); }
-    XU(sx, PW_SX) XU(sy, PW_SY) X3(sum, PW_SUM) X3(dprim, PW_DPRIM) XF(prim_t, PW_PRIMT) XI(prim_tri, PW_PRIMTRI) XI(s, PW_S)
-    X3(o, PW_O) X3(d, PW_D) X3(thr, PW_THR) X3(rad, PW_RAD) X3(n, PW_N) X3(col, PW_COL) X3(lp, PW_LP) XF(lpdf, PW_LPDF)
-    XI(li, PW_LI) XI(attempts, PW_ATT) XI(bounce, PW_BOUNCE) XI(stage, PW_STAGE)
+    XU(sx, PW_SX) XU(sy, PW_SY) X3(sum, PW_SUM) XI(s, PW_S) X3(thr, PW_THR) X3(rad, PW_RAD) X3(n, PW_N) X3(col, PW_COL) X3(lp, PW_LP)
+    XF(lpdf, PW_LPDF) XI(li, PW_LI)
 #undef X3
 #undef XF
 #undef XI
 #undef XU
+    __device__ __forceinline__ V3 o() const { return ro; }
+    __device__ __forceinline__ void set_o(V3 v) const { ro = v; }
+    __device__ __forceinline__ V3 d() const { return rd; }
+    __device__ __forceinline__ void set_d(V3 v) const { rd = v; }
+    __device__ __forceinline__ uint32_t pix() const { return (uint32_t)L.ldi(PW_PIX); }
+    __device__ __forceinline__ V3 dprim() const { const uint32_t px = pix(); return primary_dir(P, px % P.W, px / P.W); }
+    __device__ __forceinline__ void set_dprim(V3) const {}
+    __device__ __forceinline__ float prim_t() const { return prim_t_[pix()]; }
+    __device__ __forceinline__ void set_prim_t(float) const {}
+    __device__ __forceinline__ int prim_tri() const { return prim_tri_[pix()]; }
+    __device__ __forceinline__ void set_prim_tri(int) const {}
+    __device__ __forceinline__ int attempts() const { return L.ldi(PW_PACK) & 0xFF; }
+    __device__ __forceinline__ void set_attempts(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & ~0xFF) | (v & 0xFF)); }
+    __device__ __forceinline__ int stage() const { return (L.ldi(PW_PACK) >> 8) & 0xFF; }
+    __device__ __forceinline__ void set_stage(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & ~0xFF00) | ((v & 0xFF) << 8)); }
+    __device__ __forceinline__ int bounce() const { return (int)((uint32_t)L.ldi(PW_PACK) >> 16); }
+    __device__ __forceinline__ void set_bounce(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & 0xFFFF) | (v << 16)); }
 };
 
 enum { F_ALIVE = 1, F_TASK = 2, F_TRAV = 4, F_CACHED = 8 };
@@ -183,7 +203,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
             bool want_task = need_shade && !(flags & F_TASK);
             bool start_trav = false;
             LocalCnt c = {};
-            PathLds p{L};
+            PathLds p{L, ro, rd, P, prim_t, prim_tri};
             // (1) hand out the wave's next tasks.  Wave-uniform control flow: every lane executes the ballots, so the
             //     cursor `next` stays uniform.
             for (;;) {
@@ -201,12 +221,12 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                         uint32_t px, py;
                         if (tile_pixel(P, r >> 6, r & 63u, px, py)) {      // else: padding lane of an edge tile, draw again
                             const uint32_t pix = py * P.W + px;
-                            const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], prim_t[pix], prim_tri[pix], c);
+                            L.sti(PW_PIX, (int)pix); L.sti(PW_FRAME, (int)frame); L.sti(PW_PACK, 0);
+                            const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], 0.f, 0, c);
                             if (st == SH_DONE) {                            // max_path_length <= 0: black; draw again
                                 fb[(size_t)frame * npix + pix] = make_float4(0.f, 0.f, 0.f, 1.0f);
                                 L.sti(PW_C_PF, L.ldi(PW_C_PF) + 1);
                             } else {
-                                L.sti(PW_PIX, (int)pix); L.sti(PW_FRAME, (int)frame);
                                 flags |= F_TASK;
                                 want_task = false;
                                 if (st == SH_CACHED) { flags |= F_CACHED; run_shade = true; }
@@ -242,7 +262,6 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
             }
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
-                ro = p.o(); rd = p.d();
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                 best = 1.0e38f; limit = 3.0e38f; best_tri = -1;
                 i = 0; nq = 0; k = 0; kend = 0;
