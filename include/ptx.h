@@ -103,8 +103,9 @@ int ptx_upload_scene(ptx_ctx *ctx, const ptx_scene *scene);
 /* Replaces the uniform block of main.js:290-308. Resets the accumulation when the size changes. */
 int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
 /* Tuning / test switches (no reference counterpart). Keys:
- *   "traversal" : 0 = literal threaded traversal of glsl:207-249 (every box-hit node visited),
- *                 1 = same traversal + conservative best-t pruning (default; identical results)
+ *   "traversal" : bit 0 = conservative best-t pruning, bit 1 = walk the leaf-SAH tree (same leaves, same results,
+ *                 about half the box tests; DESIGN.md "Leaf-SAH tree").  0 = literal threaded traversal of
+ *                 glsl:207-249 on the reference tree, 1 = + pruning, 2 = leaf-SAH tree, 3 = both (default)
  *   "memo"      : 1 = reuse the per-pixel primary hit and the last light-attempt ray for the shadow ray
  *                 (default; both are bit-identical rays in the reference), 0 = trace every ray
  *   "count"     : 1 = also count node visits / triangle tests (slower), 0 = off (default)

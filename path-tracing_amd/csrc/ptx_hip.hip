@@ -7,6 +7,7 @@
 #include "ptx_wave.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -108,6 +109,8 @@ struct ptx_ctx {
     // scene
     bool have_scene = false;
     DScene S = {};
+    const float4* nodes_sah = nullptr;   // leaf-SAH tree over the reference leaves (same record format), or nullptr
+    int N_sah = 0;
     std::vector<void*> scene_allocs;
 
     // params
@@ -126,7 +129,7 @@ struct ptx_ctx {
     size_t ts_cap = 0;
 
     // options
-    int opt_traversal = 1, opt_memo = 1, opt_count = 0, opt_pipeline = 1, opt_frame_batch = 0, opt_tasks_per_wave = 128;
+    int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 1, opt_frame_batch = 0, opt_tasks_per_wave = 128;
 
     // counters + timing
     unsigned long long* d_counters = nullptr;
@@ -137,6 +140,14 @@ struct ptx_ctx {
 };
 
 static std::string g_create_error;
+
+// traversal option: bit 0 = best-t pruning, bit 1 = walk the leaf-SAH tree instead of the reference tree
+static inline bool opt_prune(const ptx_ctx* c) { return (c->opt_traversal & 1) != 0; }
+static inline DScene scene_view(const ptx_ctx* c) {
+    DScene S = c->S;
+    if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; }
+    return S;
+}
 
 #define HIP_TRY(ctx, expr)                                                                               \
     do {                                                                                                 \
@@ -238,6 +249,117 @@ static int upload(ptx_ctx* ctx, const std::vector<T>& h, const T** out) {
     return PTX_OK;
 }
 
+// ---------------------------------------------------------------------------------- leaf-SAH tree (traversal bit 1)
+// The reference's closest hit only depends on WHICH LEAVES have their own box hit: every ancestor box contains its
+// children's boxes exactly (unions taken in f64, each rounded once to f32; rounding is monotone), and the slab test
+// (glsl:175-191) is monotone in the box bounds operation by operation (sub, mul, min, max are all monotone, and with
+// minNum/maxNum a 0*inf = NaN slab can only occur for the smaller box), so "leaf box hit" implies "all ancestors hit".
+// The hierarchy above the leaves is therefore free: we rebuild it with a surface-area heuristic over the reference
+// leaves' exact boxes, taking exact float min/max unions for the new inner boxes, and the same threaded walk finds
+// exactly the same set of leaves with about half the box tests on pixar_room.  Leaves are visited in a different order,
+// so the winner among equal t is chosen by inorder slot explicitly (closest_hit's (t, k) compare).
+// Returns false when the reference arrays do not have that containment property (then the reference tree is walked).
+struct SahItem { float mn[3], mx[3]; int fc; float cen[3]; double w; };
+
+static bool ref_tree_is_monotone(const ptx_scene* sc) {
+    const uint32_t N = sc->N;
+    std::vector<uint32_t> end(N, 0);
+    // children of an inner node i: L = i + 1, R = miss[L]; the subtree of i ends at miss[i] (or N)
+    for (uint32_t i = 0; i < N; i++) {
+        const int32_t m = sc->node_miss[i];
+        end[i] = m < 0 ? N : (uint32_t)m;
+    }
+    for (uint32_t i = 0; i < N; i++) {
+        if (sc->node_first[i] != -2) { if (end[i] != i + 1 && !(sc->node_miss[i] == -1 && i + 1 == N)) return false; continue; }
+        const uint32_t L = i + 1;
+        if (L >= N) return false;
+        const uint32_t R = end[L];
+        if (R >= N || R <= L || end[R] != end[i]) return false;
+        for (uint32_t c : {L, R})
+            for (int k = 0; k < 3; k++)
+                if (!(sc->node_min[3 * (size_t)i + k] <= sc->node_min[3 * (size_t)c + k]) || !(sc->node_max[3 * (size_t)i + k] >= sc->node_max[3 * (size_t)c + k])) return false;
+    }
+    return true;
+}
+
+static double half_area(const float* mn, const float* mx) {
+    const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+static uint32_t sah_build(std::vector<SahItem>& items, std::vector<uint32_t>& ids, size_t lo, size_t hi, std::vector<float4>& out,
+                          std::vector<int32_t>& miss_fix) {
+    auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    const uint32_t me = (uint32_t)(out.size() / 2);
+    out.push_back(make_float4(0, 0, 0, 0)); out.push_back(make_float4(0, 0, 0, 0));
+    miss_fix.push_back(0);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t q = lo; q < hi; q++)
+        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], items[ids[q]].mn[k]); mx[k] = std::max(mx[k], items[ids[q]].mx[k]); }
+    int fc = -2;
+    if (hi - lo == 1) {
+        fc = items[ids[lo]].fc;
+    } else {
+        const size_t n = hi - lo;
+        double best = INFINITY; int best_axis = 0; size_t best_k = n / 2;
+        std::vector<uint32_t> order(n);
+        std::vector<double> right_cost(n + 1);
+        for (int ax = 0; ax < 3; ax++) {
+            std::copy(ids.begin() + lo, ids.begin() + hi, order.begin());
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return items[a].cen[ax] < items[b].cen[ax]; });
+            float rmn[3] = {INFINITY, INFINITY, INFINITY}, rmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            double rw = 0;
+            for (size_t q = n; q-- > 1;) {
+                for (int k = 0; k < 3; k++) { rmn[k] = std::min(rmn[k], items[order[q]].mn[k]); rmx[k] = std::max(rmx[k], items[order[q]].mx[k]); }
+                rw += items[order[q]].w;
+                right_cost[q] = half_area(rmn, rmx) * rw;
+            }
+            float lmn[3] = {INFINITY, INFINITY, INFINITY}, lmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            double lw = 0;
+            for (size_t q = 0; q + 1 < n; q++) {
+                for (int k = 0; k < 3; k++) { lmn[k] = std::min(lmn[k], items[order[q]].mn[k]); lmx[k] = std::max(lmx[k], items[order[q]].mx[k]); }
+                lw += items[order[q]].w;
+                const double cost = half_area(lmn, lmx) * lw + right_cost[q + 1];
+                if (cost < best) { best = cost; best_axis = ax; best_k = q + 1; }
+            }
+        }
+        std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](uint32_t a, uint32_t b) { return items[a].cen[best_axis] < items[b].cen[best_axis]; });
+        sah_build(items, ids, lo, lo + best_k, out, miss_fix);
+        sah_build(items, ids, lo + best_k, hi, out, miss_fix);
+    }
+    miss_fix[me] = (int32_t)(out.size() / 2);   // first pre-order index after this subtree
+    out[2 * (size_t)me] = make_float4(mn[0], mn[1], mn[2], 0.f);
+    out[2 * (size_t)me + 1] = make_float4(mx[0], mx[1], mx[2], bits(fc));
+    return me;
+}
+
+static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out) {
+    if (!ref_tree_is_monotone(sc)) return false;
+    std::vector<SahItem> items;
+    for (uint32_t i = 0; i < sc->N; i++) {
+        if (sc->node_first[i] == -2) continue;
+        SahItem it;
+        for (int k = 0; k < 3; k++) {
+            it.mn[k] = sc->node_min[3 * (size_t)i + k]; it.mx[k] = sc->node_max[3 * (size_t)i + k];
+            it.cen[k] = 0.5f * it.mn[k] + 0.5f * it.mx[k];
+        }
+        it.fc = sc->node_first[i] | (sc->node_count[i] << 24);
+        it.w = std::max(1, sc->node_count[i]);
+        items.push_back(it);
+    }
+    if (items.empty()) return false;
+    std::vector<uint32_t> ids(items.size());
+    for (uint32_t q = 0; q < ids.size(); q++) ids[q] = q;
+    std::vector<int32_t> miss;
+    out.clear();
+    out.reserve(items.size() * 4);
+    sah_build(items, ids, 0, ids.size(), out, miss);
+    const int32_t N2 = (int32_t)(out.size() / 2);
+    auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    for (int32_t i = 0; i < N2; i++) out[2 * (size_t)i].w = bits(miss[i] < N2 ? miss[i] : -1);
+    return true;
+}
+
 extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     if (!ctx) return PTX_ERR_INVALID;
     if (!sc) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: scene is NULL");
@@ -311,6 +433,14 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         return rc;
     }
     S.N = (int)N; S.T = (int)T; S.L = (int)L;
+    ctx->nodes_sah = nullptr; ctx->N_sah = 0;
+    {
+        std::vector<float4> sah;
+        if (build_leaf_sah(sc, sah)) {
+            if ((rc = upload(ctx, sah, &ctx->nodes_sah))) { free_scene(ctx); return rc; }
+            ctx->N_sah = (int)(sah.size() / 2);
+        }
+    }
     ctx->S = S;
     ctx->have_scene = true;
     ctx->prim_valid = false;
@@ -361,7 +491,7 @@ extern "C" int ptx_set_params(ptx_ctx* ctx, const ptx_params* p) {
 extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return PTX_ERR_INVALID;
     const std::string k(key);
-    if (k == "traversal" && (value == 0 || value == 1)) { ctx->opt_traversal = (int)value; ctx->prim_valid = false; }
+    if (k == "traversal" && value >= 0 && value <= 3) { ctx->opt_traversal = (int)value; ctx->prim_valid = false; }
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value == 0 || value == 1)) ctx->opt_pipeline = (int)value;
@@ -375,10 +505,10 @@ static int ensure_primary(ptx_ctx* ctx, float4* d_dirs) {
     if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "scene and params must be set first");
     if (ctx->prim_valid && !d_dirs) return PTX_OK;
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
-    if (ctx->opt_traversal)
-        hipLaunchKernelGGL(k_primary<true>, dim3(tiles), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
+    if (opt_prune(ctx))
+        hipLaunchKernelGGL(k_primary<true>, dim3(tiles), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
     else
-        hipLaunchKernelGGL(k_primary<false>, dim3(tiles), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
+        hipLaunchKernelGGL(k_primary<false>, dim3(tiles), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
     HIP_TRY(ctx, hipGetLastError());
     ctx->prim_valid = true;
     return PTX_OK;
@@ -403,7 +533,7 @@ static void drain_events(ptx_ctx* ctx) { // stream must be idle
 
 template <bool PRUNE, bool MEMO, bool COUNT>
 static void launch_render(ptx_ctx* ctx, uint32_t tiles, uint32_t nf) {
-    hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_ts, ctx->d_prim_t,
+    hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
                        ctx->d_prim_tri, ctx->d_fb, ctx->d_counters);
 }
 
@@ -413,7 +543,7 @@ static void launch_render_wave(ptx_ctx* ctx, uint32_t nf) {
     const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32: ptx_render_frames caps the batch
     const uint32_t per_wave = (uint32_t)ctx->opt_tasks_per_wave;
     const uint32_t blocks = (uint32_t)((total + per_wave - 1) / per_wave);
-    hipLaunchKernelGGL((k_render_wave<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->S, ctx->P, ctx->d_ts, ctx->d_prim_t,
+    hipLaunchKernelGGL((k_render_wave<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
                        ctx->d_prim_tri, ctx->d_fb, nf, per_wave, ctx->d_counters);
 }
 
@@ -456,7 +586,7 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ts, timestamps + f0, nf * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
         hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-        const int sel = (ctx->opt_traversal ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
+        const int sel = (opt_prune(ctx) ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
         if (ctx->opt_pipeline == 1) {
             switch (sel) {
                 case 0: launch_render_wave<false, false, false>(ctx, nf); break;
@@ -562,8 +692,8 @@ extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, u
     if (e == hipSuccess) e = hipMemcpy(d_d, d, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const uint32_t blocks = (n + 63) / 64;
-        if (ctx->opt_traversal) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(64), 0, ctx->stream, ctx->S, d_o, d_d, n, d_t, d_tri, ctx->d_counters);
-        else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(64), 0, ctx->stream, ctx->S, d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+        if (opt_prune(ctx)) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+        else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

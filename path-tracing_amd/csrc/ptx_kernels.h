@@ -108,6 +108,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float best = 1.0e38f;
     int best_tri = -1;
+    uint32_t best_k = 0xFFFFFFFFu;        // inorder slot of the winner: ties on t go to the smaller slot (reference order)
     uint32_t i = 0;                       // -1 (end) wraps to 0xFFFFFFFF >= N
     const uint32_t N = (uint32_t)S.N;
     float limit = 3.0e38f;
@@ -154,8 +155,9 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
             const float4 e2 = ld16(S.tris, k * 48u + 32u);
             if (COUNT) c.tri_tests++;
             float t;
-            if (tri_test(o, d, mk(v0), mk(e1), mk(e2), t) && t < best) {
+            if (tri_test(o, d, mk(v0), mk(e1), mk(e2), t) && (t < best || (t == best && k < best_k))) {
                 best = t;
+                best_k = k;
                 best_tri = __float_as_int(v0.w);
                 if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
             }

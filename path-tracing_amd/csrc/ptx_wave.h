@@ -118,6 +118,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
     V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f), inv = mk(0.f, 0.f, 0.f);
     float best = 1.0e38f, limit = 3.0e38f;
     int best_tri = -1;
+    uint32_t best_k = 0xFFFFFFFFu;
     uint32_t i = 0xFFFFFFFFu;
     const uint32_t N = (uint32_t)S.N;
     int q[PTX_WAVE_QUEUE];
@@ -188,8 +189,9 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                     if (k + u < kend) {
                         if (COUNT) cnt_tris++;
                         float t;
-                        if (tri_test(ro, rd, mk(tv0[u]), mk(te1[u]), mk(te2[u]), t) && t < best) {
+                        if (tri_test(ro, rd, mk(tv0[u]), mk(te1[u]), mk(te2[u]), t) && (t < best || (t == best && k + u < best_k))) {
                             best = t;
+                            best_k = k + u;
                             best_tri = __float_as_int(tv0[u].w);
                             if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
                         }
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                best = 1.0e38f; limit = 3.0e38f; best_tri = -1;
+                best = 1.0e38f; limit = 3.0e38f; best_tri = -1; best_k = 0xFFFFFFFFu;
                 i = 0; nq = 0; k = 0; kend = 0;
                 flags |= F_TRAV;
                 c.rays_traced++;

@@ -22,7 +22,7 @@ def setup(ctx, ptx, name, w, h, spp=4, bounces=4, **opts):
     p = ptx.config_params(name, w, h, spp, bounces)
     ctx.upload_scene(s)
     ctx.set_params(p)
-    for k, v in {**dict(traversal=1, memo=1, count=0, frame_batch=0), **opts}.items():
+    for k, v in {**dict(traversal=3, memo=1, count=0, frame_batch=0, pipeline=1, tasks_per_wave=128), **opts}.items():
         ctx.set_option(k, v)
     ctx.reset_accum()
     ctx.reset_counters()
@@ -31,7 +31,7 @@ def setup(ctx, ptx, name, w, h, spp=4, bounces=4, **opts):
 
 @pytest.mark.parametrize("name", SCENES)
 @pytest.mark.parametrize("size", [(96, 54), (40, 64), (33, 33)])
-@pytest.mark.parametrize("traversal", [0, 1])
+@pytest.mark.parametrize("traversal", [0, 1, 2, 3])
 def test_primary_dirs_and_hits_bit_exact(gpu_ctx, ptx, orc, name, size, traversal):
     s, p = setup(gpu_ctx, ptx, name, *size, traversal=traversal)
     assert (bits(gpu_ctx.primary_dirs()) == bits(orc.primary_dirs(p))).all()
@@ -58,7 +58,7 @@ def random_rays(s, n, seed):
 
 
 @pytest.mark.parametrize("name", SCENES)
-@pytest.mark.parametrize("traversal", [0, 1])
+@pytest.mark.parametrize("traversal", [0, 1, 2, 3])
 def test_trace_closest_bit_exact(gpu_ctx, ptx, orc, name, traversal):
     s, _ = setup(gpu_ctx, ptx, name, 8, 8, traversal=traversal)
     o, d = random_rays(s, 20000, 7)
@@ -70,8 +70,10 @@ def test_trace_closest_bit_exact(gpu_ctx, ptx, orc, name, traversal):
     assert k["rays"] == 20000 and k["ray_hits"] == c["ray_hits"]
     if traversal == 0:                                                  # literal traversal does the reference's work exactly
         assert k["node_visits"] == c["node_visits"] and k["tri_tests"] == c["tri_tests"]
+    elif traversal == 2:                                                # leaf-SAH tree: exactly the same leaves are hit
+        assert k["tri_tests"] == c["tri_tests"]
     else:
-        assert k["node_visits"] <= c["node_visits"] and k["tri_tests"] <= c["tri_tests"]
+        assert k["tri_tests"] <= c["tri_tests"]
 
 
 def test_trace_closest_empty_and_single(gpu_ctx, ptx, orc):
@@ -84,9 +86,10 @@ def test_trace_closest_empty_and_single(gpu_ctx, ptx, orc):
 
 @pytest.mark.parametrize("name,size,spp,bounces", [("cornell", (48, 48), 4, 4), ("my_cornell_6", (64, 64), 4, 5), ("bedroom2_v5", (64, 36), 3, 4),
                                                    ("teapot", (64, 36), 3, 4), ("pixar_room", (96, 54), 4, 8), ("pixar_room", (27, 45), 2, 12)])
-@pytest.mark.parametrize("traversal,memo", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_frames_bit_exact_and_counters(gpu_ctx, ptx, orc, name, size, spp, bounces, traversal, memo):
-    s, p = setup(gpu_ctx, ptx, name, *size, spp=spp, bounces=bounces, traversal=traversal, memo=memo, count=1)
+@pytest.mark.parametrize("traversal,memo,pipeline", [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (2, 1, 0), (3, 1, 0),
+                                                     (0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1), (2, 0, 1), (3, 1, 1)])
+def test_frames_bit_exact_and_counters(gpu_ctx, ptx, orc, name, size, spp, bounces, traversal, memo, pipeline):
+    s, p = setup(gpu_ctx, ptx, name, *size, spp=spp, bounces=bounces, traversal=traversal, memo=memo, count=1, pipeline=pipeline)
     ts = ptx.scene.timestamps(3)
     gpu_ctx.render_frames(ts)
     got = gpu_ctx.read_sum()
@@ -218,12 +221,17 @@ def test_full_size_properties(gpu_ctx, ptx, orc, cfg):
     ts = ptx.scene.timestamps(2)
     # (1) primary hits: literal == pruned over the whole image, and == oracle on sampled rows
     gpu_ctx.set_option("traversal", 0); t0, tri0 = gpu_ctx.primary_hits()
-    gpu_ctx.set_option("traversal", 1); t1, tri1 = gpu_ctx.primary_hits()
-    assert (tri0 == tri1).all() and (bits(t0) == bits(t1)).all()
-    # (2) one frame: pruned+memo == literal+no-memo (the reference's every-ray algorithm), whole image, bit for bit
-    gpu_ctx.set_option("traversal", 0); gpu_ctx.set_option("memo", 0)
+    for trav in (1, 2, 3):
+        gpu_ctx.set_option("traversal", trav); t1, tri1 = gpu_ctx.primary_hits()
+        assert (tri0 == tri1).all() and (bits(t0) == bits(t1)).all(), trav
+    # (2) one frame: the default (leaf-SAH tree + pruning + memo, wave pipeline) == the reference's every-ray algorithm
+    #     (literal traversal of the reference tree, no memo, one ray at a time), whole image, bit for bit
+    gpu_ctx.set_option("traversal", 0); gpu_ctx.set_option("memo", 0); gpu_ctx.set_option("pipeline", 0)
     gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); lit = gpu_ctx.read_sum()
-    gpu_ctx.set_option("traversal", 1); gpu_ctx.set_option("memo", 1)
+    gpu_ctx.set_option("traversal", 2); gpu_ctx.set_option("memo", 1); gpu_ctx.set_option("pipeline", 1)
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); sah = gpu_ctx.read_sum()
+    assert (bits(lit) == bits(sah)).all()
+    gpu_ctx.set_option("traversal", 3)
     gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); fa = gpu_ctx.read_sum()
     assert (bits(lit) == bits(fa)).all()
     # (3) linearity of the accumulation: frames {a,b} together == a + b

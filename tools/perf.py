@@ -16,12 +16,13 @@ for kv in filter(None, os.environ.get("PERF_OPTS", "").split(",")):
 nfr = int(os.environ.get("PERF_FRAMES", "2"))
 ref = np.load(os.path.join(ROOT, "tests", "golden", "frames.npz"))
 imgs = {}
-for trav in [int(x) for x in os.environ.get("PERF_TRAV", "0,1").split(",")]:
+for trav in [int(x) for x in os.environ.get("PERF_TRAV", "0,3").split(",")]:
     ctx.set_option("traversal", trav)
     ctx.reset_accum(); ctx.render_frames([999]); ctx.synchronize()   # warm
     ctx.reset_accum(); ctx.reset_counters()
     t0 = time.time(); ctx.render_frames(list(range(1000, 1000 + nfr))); ctx.synchronize(); dt = time.time() - t0
     k = ctx.counters(); imgs[trav] = ctx.read_sum()
     print(f"{os.environ.get('PTX_LIB_PATH','default'):<40} {cfg} trav={trav} opts={os.environ.get('PERF_OPTS','')} ms/frame={dt*1000/nfr:.1f} Msamples/s={k['samples']/dt/1e6:.1f} Mrays/s={k['rays']/dt/1e6:.0f}", flush=True)
-if len(imgs) == 2:
-    print("   literal==pruned:", bool((imgs[0].view(np.uint32) == imgs[1].view(np.uint32)).all()), flush=True)
+ks = sorted(imgs)
+for k in ks[1:]:
+    print(f"   trav {ks[0]} == trav {k}:", bool((imgs[ks[0]].view(np.uint32) == imgs[k].view(np.uint32)).all()), flush=True)
