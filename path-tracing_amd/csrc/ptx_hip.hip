@@ -109,7 +109,7 @@ struct ptx_ctx {
     // scene
     bool have_scene = false;
     DScene S = {};
-    const float4* nodes_sah = nullptr;   // leaf-SAH tree over the reference leaves (same record format), or nullptr
+    const float4* nodes_sah = nullptr;   // leaf-SAH tree over the reference leaves: 8 direction-octant layouts, or nullptr
     int N_sah = 0;
     std::vector<void*> scene_allocs;
 
@@ -145,7 +145,7 @@ static std::string g_create_error;
 static inline bool opt_prune(const ptx_ctx* c) { return (c->opt_traversal & 1) != 0; }
 static inline DScene scene_view(const ptx_ctx* c) {
     DScene S = c->S;
-    if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; }
+    if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; S.oct_stride = (uint32_t)c->N_sah * 32u; }
     return S;
 }
 
@@ -287,18 +287,19 @@ static double half_area(const float* mn, const float* mx) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-static uint32_t sah_build(std::vector<SahItem>& items, std::vector<uint32_t>& ids, size_t lo, size_t hi, std::vector<float4>& out,
-                          std::vector<int32_t>& miss_fix) {
-    auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    const uint32_t me = (uint32_t)(out.size() / 2);
-    out.push_back(make_float4(0, 0, 0, 0)); out.push_back(make_float4(0, 0, 0, 0));
-    miss_fix.push_back(0);
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+struct SahNode { float mn[3], mx[3]; int fc; int left, right, axis; };
+
+// top-down SAH over ids[lo, hi): returns the index of the node created in `tree`
+static int sah_build(std::vector<SahItem>& items, std::vector<uint32_t>& ids, size_t lo, size_t hi, std::vector<SahNode>& tree) {
+    const int me = (int)tree.size();
+    tree.push_back(SahNode());
+    SahNode nd;
+    for (int k = 0; k < 3; k++) { nd.mn[k] = INFINITY; nd.mx[k] = -INFINITY; }
     for (size_t q = lo; q < hi; q++)
-        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], items[ids[q]].mn[k]); mx[k] = std::max(mx[k], items[ids[q]].mx[k]); }
-    int fc = -2;
+        for (int k = 0; k < 3; k++) { nd.mn[k] = std::min(nd.mn[k], items[ids[q]].mn[k]); nd.mx[k] = std::max(nd.mx[k], items[ids[q]].mx[k]); }
+    nd.fc = -2; nd.left = nd.right = -1; nd.axis = 0;
     if (hi - lo == 1) {
-        fc = items[ids[lo]].fc;
+        nd.fc = items[ids[lo]].fc;
     } else {
         const size_t n = hi - lo;
         double best = INFINITY; int best_axis = 0; size_t best_k = n / 2;
@@ -324,16 +325,33 @@ static uint32_t sah_build(std::vector<SahItem>& items, std::vector<uint32_t>& id
             }
         }
         std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](uint32_t a, uint32_t b) { return items[a].cen[best_axis] < items[b].cen[best_axis]; });
-        sah_build(items, ids, lo, lo + best_k, out, miss_fix);
-        sah_build(items, ids, lo + best_k, hi, out, miss_fix);
+        nd.axis = best_axis;
+        nd.left = sah_build(items, ids, lo, lo + best_k, tree);      // lower side along the split axis
+        nd.right = sah_build(items, ids, lo + best_k, hi, tree);     // upper side
     }
-    miss_fix[me] = (int32_t)(out.size() / 2);   // first pre-order index after this subtree
-    out[2 * (size_t)me] = make_float4(mn[0], mn[1], mn[2], 0.f);
-    out[2 * (size_t)me + 1] = make_float4(mx[0], mx[1], mx[2], bits(fc));
+    tree[me] = nd;
     return me;
 }
 
-static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out) {
+// pre-order flattening of `tree` for rays whose direction signs are `oct` (bit k set = d[k] < 0): the child on the
+// side the ray comes from is visited first, so the threaded walk is roughly front-to-back and best-t pruning bites
+// early.  Which nodes are visited WITHOUT pruning does not depend on the order, so the hit leaves are unchanged.
+static void sah_flatten(const std::vector<SahNode>& tree, int node, int oct, std::vector<float4>& out, size_t base) {
+    auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+    const SahNode& nd = tree[node];
+    const size_t me = out.size() / 2 - base;
+    out.push_back(make_float4(nd.mn[0], nd.mn[1], nd.mn[2], 0.f));
+    out.push_back(make_float4(nd.mx[0], nd.mx[1], nd.mx[2], bits(nd.fc)));
+    if (nd.left >= 0) {
+        const bool neg = (oct >> nd.axis) & 1;
+        sah_flatten(tree, neg ? nd.right : nd.left, oct, out, base);
+        sah_flatten(tree, neg ? nd.left : nd.right, oct, out, base);
+    }
+    out[2 * (base + me)].w = bits((int32_t)(out.size() / 2 - base));   // first pre-order index after this subtree (fixed below)
+}
+
+// out: 8 layouts (one per direction octant) of N2 nodes each, same 32-B record format as the reference tree
+static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n2) {
     if (!ref_tree_is_monotone(sc)) return false;
     std::vector<SahItem> items;
     for (uint32_t i = 0; i < sc->N; i++) {
@@ -350,13 +368,22 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out) {
     if (items.empty()) return false;
     std::vector<uint32_t> ids(items.size());
     for (uint32_t q = 0; q < ids.size(); q++) ids[q] = q;
-    std::vector<int32_t> miss;
+    std::vector<SahNode> tree;
+    tree.reserve(items.size() * 2);
+    sah_build(items, ids, 0, ids.size(), tree);
+    const int32_t N2 = (int32_t)tree.size();
     out.clear();
-    out.reserve(items.size() * 4);
-    sah_build(items, ids, 0, ids.size(), out, miss);
-    const int32_t N2 = (int32_t)(out.size() / 2);
+    out.reserve((size_t)N2 * 16);
     auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    for (int32_t i = 0; i < N2; i++) out[2 * (size_t)i].w = bits(miss[i] < N2 ? miss[i] : -1);
+    for (int oct = 0; oct < 8; oct++) {
+        const size_t base = (size_t)oct * N2;
+        sah_flatten(tree, 0, oct, out, base);
+        for (int32_t i = 0; i < N2; i++) {
+            int32_t m; std::memcpy(&m, &out[2 * (base + i)].w, 4);
+            if (m >= N2) out[2 * (base + i)].w = bits(-1);
+        }
+    }
+    *n2 = N2;
     return true;
 }
 
@@ -436,9 +463,10 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     ctx->nodes_sah = nullptr; ctx->N_sah = 0;
     {
         std::vector<float4> sah;
-        if (build_leaf_sah(sc, sah)) {
+        int n2 = 0;
+        if (build_leaf_sah(sc, sah, &n2)) {
             if ((rc = upload(ctx, sah, &ctx->nodes_sah))) { free_scene(ctx); return rc; }
-            ctx->N_sah = (int)(sah.size() / 2);
+            ctx->N_sah = n2;
         }
     }
     ctx->S = S;

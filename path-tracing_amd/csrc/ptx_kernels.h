@@ -22,6 +22,7 @@ struct DScene {
     const float4* attrE;
     const float4* light;   // 6 float4 per light
     int N, T, L;
+    uint32_t oct_stride;   // bytes between the 8 direction-octant layouts of `nodes` (0: a single layout)
 };
 
 struct DParams {
@@ -92,6 +93,9 @@ __device__ __forceinline__ float4 ld16(const float4* base, uint32_t byte_off) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// direction octant of a ray: bit k set = d[k] < 0 (selects the node layout whose child order is front-to-back)
+__device__ __forceinline__ uint32_t octant(V3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
+
 // Leaves whose box was hit are collected PTX_LEAF_BATCH at a time before their triangles are tested, so the
 // lanes of a wave spend their time in two tight loops (node walk / triangle tests) instead of waiting on each
 // other's leaf loops inside the walk.  Legal because the threaded walk never depends on triangle results
@@ -112,14 +116,15 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
     uint32_t i = 0;                       // -1 (end) wraps to 0xFFFFFFFF >= N
     const uint32_t N = (uint32_t)S.N;
     float limit = 3.0e38f;
+    const uint32_t nbase = octant(d) * S.oct_stride;
     do {
         int pend[PTX_LEAF_BATCH];
         int n = 0;
         uint32_t it_walk = 0, it_tri = 0;
         while (n < PTX_LEAF_BATCH && i < N) {
             if (COUNT) it_walk++;
-            const float4 a = ld16(S.nodes, i << 5);
-            const float4 b = ld16(S.nodes, (i << 5) + 16);
+            const float4 a = ld16(S.nodes, nbase + (i << 5));
+            const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
             if (COUNT) c.node_visits++;
             float tn;
             bool hit = slab_test(o, inv, mk(a), mk(b), tn);

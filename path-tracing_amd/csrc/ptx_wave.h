@@ -24,7 +24,7 @@
 #define PTX_WAVE_SHADE_MIN 12     // run SHADE once this many lanes wait for it (or nothing else can run)
 #endif
 #ifndef PTX_WAVE_TRI_MIN
-#define PTX_WAVE_TRI_MIN 24
+#define PTX_WAVE_TRI_MIN 48
 #endif
 #ifndef PTX_WAVE_MIN_WAVES
 #define PTX_WAVE_MIN_WAVES 1      // __launch_bounds__ waves per SIMD (caps VGPRs: 4 -> 128, 5 -> 96)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
     float best = 1.0e38f, limit = 3.0e38f;
     int best_tri = -1;
     uint32_t best_k = 0xFFFFFFFFu;
-    uint32_t i = 0xFFFFFFFFu;
+    uint32_t i = 0xFFFFFFFFu, nbase = 0;
     const uint32_t N = (uint32_t)S.N;
     int q[PTX_WAVE_QUEUE];
     int nq = 0;
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
 #pragma unroll
             for (int u = 0; u < PTX_WAVE_WALK_STEPS; u++) {
                 if (trav && i < N && nq < PTX_WAVE_QUEUE) {
-                    const float4 a = ld16(S.nodes, i << 5);
-                    const float4 b = ld16(S.nodes, (i << 5) + 16);
+                    const float4 a = ld16(S.nodes, nbase + (i << 5));
+                    const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
                     if (COUNT) cnt_nodes++;
                     float tn;
                     bool hit = slab_test(ro, inv, mk(a), mk(b), tn);
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                nbase = octant(rd) * S.oct_stride;
                 best = 1.0e38f; limit = 3.0e38f; best_tri = -1; best_k = 0xFFFFFFFFu;
                 i = 0; nq = 0; k = 0; kend = 0;
                 flags |= F_TRAV;
