@@ -30,6 +30,16 @@ def algorithmic_bytes(fr):
     return 36 * fr["node_visits"] + 40 * fr["tri_tests"] + 36 * fr["ray_hits"] + 76 * fr["light_attempts"] + 32 * fr["pixel_frames"]
 
 
+def measured_traffic(steps):
+    """HBM bytes per k_render_wave launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    KB -> B; profiles/r01_traffic.json, written by tools/traffic_from_pmc.py for the default command), else None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        return t.get(str(steps), {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(m, scene, params, seconds_target=15.0):
     """Times the CPU oracle (kind 'port') on an evenly spread row sample of frame 0 of the same workload."""
     from oracle import orc
@@ -58,19 +68,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--traversal", type=int, default=None)
+    ap.add_argument("--traversal", type=int, default=None, help="0 literal, 1 pruned, 2 leaf-SAH, 3 leaf-SAH + pruned (library default)")
+    ap.add_argument("--pipeline", type=int, default=None, help="0 one ray at a time per lane, 1 wave-scheduled (library default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + PTX_BENCH_ONE_DEVICE=1 rehearses N>1 on one GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    one_device = os.environ.get("PTX_BENCH_ONE_DEVICE", "0") == "1"      # rehearsal of the N>1 code path on a 1-GPU box
+    dev_index = 0 if (world == 1 or one_device) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
     n_gpus = world
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
+    host_reduce = world > 1 and args.backend != "nccl"
 
     m = ptx_import.load()
     cfg = m.CONFIGS[args.config]
@@ -83,6 +99,8 @@ def main():
     ctx.set_params(params)
     if args.traversal is not None:
         ctx.set_option("traversal", args.traversal)
+    if args.pipeline is not None:
+        ctx.set_option("pipeline", args.pipeline)
     K, W = args.steps, args.warmup
     accum = torch.zeros(params.height, params.width, 4, dtype=torch.float32, device=dev)
 
@@ -93,7 +111,12 @@ def main():
         ctx.render_frames([1000 + f for f in frame_ids])
         if world > 1:  # one all-reduce of the float accumulation buffer per frame batch
             ctx.accum_export_device(accum.data_ptr())
-            dist.all_reduce(accum)
+            if host_reduce:                      # gloo rehearsal: stage through the host
+                h = accum.cpu()
+                dist.all_reduce(h)
+                accum.copy_(h)
+            else:
+                dist.all_reduce(accum)           # RCCL over xGMI
             torch.cuda.current_stream().synchronize()
             ctx.accum_import_device(accum.data_ptr(), ctx.frames_done * world)
         ctx.synchronize()
@@ -114,9 +137,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rdev = torch.device("cpu") if host_reduce else dev
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
     c = ctx.counters()
-    tot = torch.tensor([c["samples"], c["rays"], c["rays_traced"]], dtype=torch.float64, device=dev)
+    tot = torch.tensor([c["samples"], c["rays"], c["rays_traced"]], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot)
@@ -137,10 +161,11 @@ def main():
             "n_gpus": n_gpus, "steps": K, "warmup": W, "ms_per_step": dt * 1e3 / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "reference scene (tests/golden/scenes/pixar_room.ptxs, flattened from resources/pixar_room/v1 by the JS host); fixed timestamps 1000+f",
             "config": {"workload": f"{args.config}: {cfg['scene']} {cfg['width']}x{cfg['height']}, {cfg['sample_count']} spp/frame, {cfg['max_path_length']} bounces, one frame per step per GPU",
-                       "frames_per_gpu": K, "traversal": "pruned" if (args.traversal in (None, 1)) else "literal",
+                       "frames_per_gpu": K, "traversal": {0: "literal (reference tree)", 1: "reference tree + best-t pruning", 2: "leaf-SAH tree", 3: "leaf-SAH tree + best-t pruning"}[3 if args.traversal is None else args.traversal],
+                       "pipeline": "wave-scheduled" if args.pipeline in (None, 1) else "one ray per lane",
                        "parallelism": f"frame-split x{n_gpus} + 1 all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_render", "kernel_ms_avg": c["kernel_ms"] / launches, "launches": launches,
+                         "traffic": measured_traffic(K), "kernel": "k_render_wave" if args.pipeline in (None, 1) else "k_render", "kernel_ms_avg": c["kernel_ms"] / launches, "launches": launches,
                          "algorithmic_bytes_per_launch": bytes_total / launches,
                          "note": "algorithmic bytes = 36Nv+40Nt+36Nh+76Nl+32Npf with the REFERENCE algorithm's counts (tests/golden/workload_counts.json); the scene is L2-resident, so this is an effective rate"},
         }
