@@ -30,7 +30,19 @@
 #define PTX_WAVE_MIN_WAVES 1      // __launch_bounds__ waves per SIMD (caps VGPRs: 4 -> 128, 5 -> 96)
 #endif
 #ifndef PTX_WAVE_WALK_STEPS
-#define PTX_WAVE_WALK_STEPS 1     // node steps per WALK phase
+#define PTX_WAVE_WALK_STEPS 12    // node steps per WALK phase (a multiple of PTX_WAVE_WALK_UNROLL)
+#endif
+#ifndef PTX_WAVE_WALK_UNROLL
+#define PTX_WAVE_WALK_UNROLL 2
+#endif
+#ifndef PTX_WAVE_WALK_KEEP
+#define PTX_WAVE_WALK_KEEP 0      // leave the WALK phase early once fewer than KEEP/8 of the lanes it started with still walk (0: never)
+#endif
+#ifndef PTX_WAVE_TRI_KEEP
+#define PTX_WAVE_TRI_KEEP 0
+#endif
+#ifndef PTX_WAVE_TRI_ROUNDS
+#define PTX_WAVE_TRI_ROUNDS 6     // rounds of PTX_WAVE_LEAF_TRIS triangle tests per TRI phase
 #endif
 #ifndef PTX_WAVE_LEAF_TRIS
 #define PTX_WAVE_LEAF_TRIS 2      // triangles of the current leaf tested per TRI phase
@@ -145,8 +157,11 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
 
         if (phase == 0) {
             if (COUNT) { d_walk += can_walk ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
+            const int keepW = (nW * PTX_WAVE_WALK_KEEP) >> 3;
+#pragma nounroll
+            for (int g = 0; g < PTX_WAVE_WALK_STEPS / PTX_WAVE_WALK_UNROLL; g++) {
 #pragma unroll
-            for (int u = 0; u < PTX_WAVE_WALK_STEPS; u++) {
+            for (int u = 0; u < PTX_WAVE_WALK_UNROLL; u++) {
                 if (trav && i < N && nq < PTX_WAVE_QUEUE) {
                     const float4 a = ld16(S.nodes, nbase + (i << 5));
                     const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
@@ -162,9 +177,15 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                     i = hit ? i + 1u : (uint32_t)__float_as_int(a.w);
                 }
             }
+            if (PTX_WAVE_WALK_KEEP && __popcll(__ballot(trav && i < N && nq < PTX_WAVE_QUEUE)) < keepW) break;
+            }
         } else if (phase == 1) {
             if (COUNT) { d_tri += has_tri ? 1u : 0u; if (lane == 0) d_tri_s += 64u; }
-            if (has_tri) {
+            const int keepT = (nT * PTX_WAVE_TRI_KEEP) >> 3;
+#pragma nounroll
+            for (int r = 0; r < PTX_WAVE_TRI_ROUNDS; r++) {
+            if (PTX_WAVE_TRI_KEEP && r && __popcll(__ballot(trav && (k < kend || nq > 0))) < keepT) break;
+            if (trav && (k < kend || nq > 0)) {
                 if (k == kend) {              // pop the oldest pending leaf
                     const int fc = q[0];
 #pragma unroll
@@ -198,6 +219,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                     }
                 }
                 k = min(k + (uint32_t)PTX_WAVE_LEAF_TRIS, kend);
+            }
             }
         } else {
             if (COUNT) { d_shade += need_shade ? 1u : 0u; if (lane == 0) d_shade_s += 64u; }
