@@ -30,12 +30,13 @@ def algorithmic_bytes(fr):
     return 36 * fr["node_visits"] + 40 * fr["tri_tests"] + 36 * fr["ray_hits"] + 76 * fr["light_attempts"] + 32 * fr["pixel_frames"]
 
 
-def measured_traffic(steps):
-    """HBM bytes per k_render_wave launch from the committed PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-    KB -> B; profiles/r01_traffic.json, written by tools/traffic_from_pmc.py for the default command), else None."""
+def measured_traffic(frames_per_launch):
+    """HBM bytes per path-tracing launch from the committed PMC passes (profiles/r01_traffic.json, written by
+    tools/traffic_from_pmc.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB -> B, per frame) x the frames one launch
+    of this run renders; None when no such profile is committed."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        return t.get(str(steps), {}).get("hbm_bytes_per_launch")
+        return t["hbm_bytes_per_frame"] * frames_per_launch
     except Exception:
         return None
 
@@ -165,7 +166,7 @@ def main():
                        "pipeline": "wave-scheduled" if args.pipeline in (None, 1) else "one ray per lane",
                        "parallelism": f"frame-split x{n_gpus} + 1 all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(K), "kernel": "k_render_wave" if args.pipeline in (None, 1) else "k_render", "kernel_ms_avg": c["kernel_ms"] / launches, "launches": launches,
+                         "traffic": measured_traffic(K / launches), "kernel": "k_render_wave" if args.pipeline in (None, 1) else "k_render", "kernel_ms_avg": c["kernel_ms"] / launches, "launches": launches,
                          "algorithmic_bytes_per_launch": bytes_total / launches,
                          "note": "algorithmic bytes = 36Nv+40Nt+36Nh+76Nl+32Npf with the REFERENCE algorithm's counts (tests/golden/workload_counts.json); the scene is L2-resident, so this is an effective rate"},
         }
