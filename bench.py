@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--config", default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traversal", type=int, default=None, help="0 literal, 1 pruned, 2 leaf-SAH, 3 leaf-SAH + pruned (library default)")
-    ap.add_argument("--pipeline", type=int, default=None, help="0 one ray at a time per lane, 1 wave-scheduled (library default)")
+    ap.add_argument("--pipeline", type=int, default=None, help="0 one ray at a time per lane, 1 wave-scheduled with per-lane leaf queues, 2 wave-scheduled with a shared leaf queue (library default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + PTX_BENCH_ONE_DEVICE=1 rehearses N>1 on one GPU")
     args = ap.parse_args()
 
@@ -163,10 +163,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "reference scene (tests/golden/scenes/pixar_room.ptxs, flattened from resources/pixar_room/v1 by the JS host); fixed timestamps 1000+f",
             "config": {"workload": f"{args.config}: {cfg['scene']} {cfg['width']}x{cfg['height']}, {cfg['sample_count']} spp/frame, {cfg['max_path_length']} bounces, one frame per step per GPU",
                        "frames_per_gpu": K, "traversal": {0: "literal (reference tree)", 1: "reference tree + best-t pruning", 2: "leaf-SAH tree", 3: "leaf-SAH tree + best-t pruning"}[3 if args.traversal is None else args.traversal],
-                       "pipeline": "wave-scheduled" if args.pipeline in (None, 1) else "one ray per lane",
+                       "pipeline": {0: "one ray per lane", 1: "wave-scheduled, per-lane leaf queues", 2: "wave-scheduled, shared leaf queue"}[2 if args.pipeline is None else args.pipeline],
                        "parallelism": f"frame-split x{n_gpus} + 1 all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(K / launches), "kernel": "k_render_wave" if args.pipeline in (None, 1) else "k_render", "kernel_ms_avg": c["kernel_ms"] / launches, "launches": launches,
+                         "traffic": measured_traffic(K / launches), "kernel": {0: "k_render", 1: "k_render_wave", 2: "k_render_pool"}[2 if args.pipeline is None else args.pipeline], "kernel_ms_avg": c["kernel_ms"] / launches, "launches": launches,
                          "algorithmic_bytes_per_launch": bytes_total / launches,
                          "note": "algorithmic bytes = 36Nv+40Nt+36Nh+76Nl+32Npf with the REFERENCE algorithm's counts (tests/golden/workload_counts.json); the scene is L2-resident, so this is an effective rate"},
         }

@@ -85,7 +85,7 @@ typedef struct ptx_counters {
     double kernel_ms;        /* HIP-event time of those launches, summed (valid after ptx_synchronize)   */
     uint64_t diag[12];       /* SIMT-efficiency diagnostics, only with option "count" = 1: lane-iterations that did work and
                                 64 x wave-iterations for {node walk, triangle tests, traversal calls}: useful, slots pairs; then shader
-                                cycles and wave-iterations per phase {walk, tri, shade} of pipeline 1 */
+                                cycles and wave-iterations per phase {walk, tri, shade} of pipelines 1 and 2 */
 } ptx_counters;
 
 /* ---- lifecycle (no reference counterpart: canvas.getContext('webgl2'), main.js:123) ---- */
@@ -109,10 +109,11 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *   "memo"      : 1 = reuse the per-pixel primary hit and the last light-attempt ray for the shadow ray
  *                 (default; both are bit-identical rays in the reference), 0 = trace every ray
  *   "count"     : 1 = also count node visits / triangle tests (slower), 0 = off (default)
- *   "pipeline"  : 0 = one lane per (pixel, frame), rays traced one at a time; 1 = wave-scheduled queues (default):
- *                 per-lane walk / triangle / shade work voted per wave, persistent lanes drawing tasks (ptx_wave.h)
+ *   "pipeline"  : 0 = one lane per (pixel, frame), rays traced one at a time; 1 = wave-scheduled, per-lane leaf queues:
+ *                 per-lane walk / triangle / shade work voted per wave, persistent lanes drawing tasks (ptx_wave.h);
+ *                 2 = wave-scheduled with one leaf queue per wave shared by its lanes (ptx_pool.h; default)
  *   "frame_batch": max frames rendered concurrently (0 = auto)
- *   "tasks_per_wave": (pixel, frame) tasks one wave of pipeline 1 works through (default 128)
+ *   "tasks_per_wave": (pixel, frame) tasks one wave of pipeline 1 / 2 works through (default 128)
  */
 int ptx_set_option(ptx_ctx *ctx, const char *key, int64_t value);
 

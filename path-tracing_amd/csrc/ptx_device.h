@@ -95,6 +95,21 @@ __device__ __forceinline__ bool slab_test(V3 o, V3 inv, V3 bmin, V3 bmax, float&
     return (tn <= tf) && (tf > 0.0f);
 }
 
+// The same slab test on a packed node record (ptx_kernels.h): a = {min.x, min.y, max.x, max.y}, b = {min.z, max.z, ..}.
+// The six subtractions and six multiplications are the same separately rounded f32 operations, issued as three
+// v_pk_add_f32 + three v_pk_mul_f32 (two lanes of a register pair per instruction).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool slab_node(V3 o, V3 inv, float4 a, float4 b, float& tNear) {
+    const f2 oxy = {o.x, o.y}, ixy = {inv.x, inv.y}, ozz = {o.z, o.z}, izz = {inv.z, inv.z};
+    const f2 lo = (f2{a.x, a.y} - oxy) * ixy;     // t1.xy
+    const f2 hi = (f2{a.z, a.w} - oxy) * ixy;     // t2.xy
+    const f2 zz = (f2{b.x, b.y} - ozz) * izz;     // t1.z, t2.z
+    float tn = fmaxf(fmaxf(fminf(lo.x, hi.x), fminf(lo.y, hi.y)), fminf(zz.x, zz.y));
+    float tf = fminf(fminf(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y)), fmaxf(zz.x, zz.y));
+    tNear = tn;
+    return (tn <= tf) && (tf > 0.0f);
+}
+
 // glsl:150-173 with edge1 = v1 - v0 and edge2 = v2 - v0 precomputed (same f32 values).
 // Straight-line form: every quantity is computed unconditionally and the shader's four early returns are folded
 // into one predicate with the SAME comparisons (so NaN operands behave exactly as in the branchy original: a NaN u or
@@ -111,6 +126,27 @@ __device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float&
     float t = f * dot(e2, q);
     t_out = t;
     return !(a > -0.0001f && a < 0.0001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0001f);
+}
+
+// Two triangles A, B at once from a pair record (ptx_kernels.h "pairs"): every quantity is an f2 {A, B}, so the 48
+// multiplications / additions of two Moeller-Trumbore tests issue as 24 packed instructions.  Operation order per
+// triangle is exactly tri_test's; a padding B (all zeros) has a = 0 and is rejected by the determinant test.
+__device__ __forceinline__ void tri_test2(V3 o, V3 d, float4 r0, float4 r1, float4 r2, float4 r3, float4 r4, bool& hitA, bool& hitB, float& tA, float& tB) {
+    const f2 v0x = {r0.x, r0.y}, v0y = {r0.z, r0.w}, v0z = {r1.x, r1.y}, e1x = {r1.z, r1.w}, e1y = {r2.x, r2.y}, e1z = {r2.z, r2.w},
+             e2x = {r3.x, r3.y}, e2y = {r3.z, r3.w}, e2z = {r4.x, r4.y};
+    const f2 dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+    const f2 hx = dy * e2z - e2y * dz, hy = dz * e2x - e2z * dx, hz = dx * e2y - e2x * dy;          // cross(d, e2)
+    const f2 a = (e1x * hx + e1y * hy) + e1z * hz;
+    const f2 f = {1.0f / a.x, 1.0f / a.y};
+    const f2 sx = f2{o.x, o.x} - v0x, sy = f2{o.y, o.y} - v0y, sz = f2{o.z, o.z} - v0z;
+    const f2 u = f * ((sx * hx + sy * hy) + sz * hz);
+    const f2 qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;          // cross(s, e1)
+    const f2 v = f * ((dx * qx + dy * qy) + dz * qz);
+    const f2 t = f * ((e2x * qx + e2y * qy) + e2z * qz);
+    const f2 uv = u + v;
+    tA = t.x; tB = t.y;
+    hitA = !(a.x > -0.0001f && a.x < 0.0001f) && !(u.x < 0.0f || u.x > 1.0f) && !(v.x < 0.0f || uv.x > 1.0f) && (t.x > 0.0001f);
+    hitB = !(a.y > -0.0001f && a.y < 0.0001f) && !(u.y < 0.0f || u.y > 1.0f) && !(v.y < 0.0f || uv.y > 1.0f) && (t.y > 0.0001f);
 }
 
 } // namespace ptx

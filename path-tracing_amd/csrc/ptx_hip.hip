@@ -5,6 +5,7 @@
 // host-side precomputation below (edges, light pdf, aspect) must round every operation separately.
 #include "../../include/ptx.h"
 #include "ptx_wave.h"
+#include "ptx_pool.h"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -129,7 +130,7 @@ struct ptx_ctx {
     size_t ts_cap = 0;
 
     // options
-    int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 1, opt_frame_batch = 0, opt_tasks_per_wave = 128;
+    int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128;
 
     // counters + timing
     unsigned long long* d_counters = nullptr;
@@ -387,6 +388,15 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n
     return true;
 }
 
+// {min.xyz, miss}, {max.xyz, fc}  ->  {min.x, min.y, max.x, max.y}, {min.z, max.z, miss, fc}   (ptx_kernels.h)
+static void repack_nodes(std::vector<float4>& n) {
+    for (size_t i = 0; i + 1 < n.size(); i += 2) {
+        const float4 a = n[i], b = n[i + 1];
+        n[i] = make_float4(a.x, a.y, b.x, b.y);
+        n[i + 1] = make_float4(a.z, b.z, a.w, b.w);
+    }
+}
+
 extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     if (!ctx) return PTX_ERR_INVALID;
     if (!sc) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: scene is NULL");
@@ -414,7 +424,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
 
-    std::vector<float4> nodes((size_t)N * 2), tris((size_t)T * 3), aN(T), aC(T), aE(T), light((size_t)L * 6);
+    std::vector<float4> nodes((size_t)N * 2), tris((size_t)T * 3), pairs((size_t)T * 5), aN(T), aC(T), aE(T), light((size_t)L * 6);
     auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     for (uint32_t i = 0; i < N; i++) {
         const float* mn = sc->node_min + 3 * (size_t)i;
@@ -430,6 +440,24 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         tris[3 * (size_t)k] = make_float4(p[0], p[1], p[2], bits(tri));
         tris[3 * (size_t)k + 1] = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.f); // glsl:151
         tris[3 * (size_t)k + 2] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.f); // glsl:152
+    }
+    for (uint32_t i = 0; i < N; i++) {   // pipeline 2: the leaves' triangles again, two per record, component-interleaved
+        if (sc->node_first[i] == -2) continue;
+        const int32_t first = sc->node_first[i], cnt = sc->node_count[i];
+        for (int32_t q = 0; 2 * q < cnt; q++) {
+            float v[2][9] = {};
+            for (int h = 0; h < 2 && 2 * q + h < cnt; h++) {
+                const float4* r = &tris[3 * (size_t)(first + 2 * q + h)];
+                const float c9[9] = {r[0].x, r[0].y, r[0].z, r[1].x, r[1].y, r[1].z, r[2].x, r[2].y, r[2].z};
+                std::memcpy(v[h], c9, sizeof(c9));
+            }
+            float4* o = &pairs[5 * (size_t)(first + q)];
+            o[0] = make_float4(v[0][0], v[1][0], v[0][1], v[1][1]);
+            o[1] = make_float4(v[0][2], v[1][2], v[0][3], v[1][3]);
+            o[2] = make_float4(v[0][4], v[1][4], v[0][5], v[1][5]);
+            o[3] = make_float4(v[0][6], v[1][6], v[0][7], v[1][7]);
+            o[4] = make_float4(v[0][8], v[1][8], bits(cnt - 2 * q), 0.f);
+        }
     }
     for (uint32_t t = 0; t < T; t++) {
         aN[t] = make_float4(sc->normals[3 * (size_t)t], sc->normals[3 * (size_t)t + 1], sc->normals[3 * (size_t)t + 2], 0.f);
@@ -454,7 +482,8 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     }
     DScene S = {};
     int rc;
-    if ((rc = upload(ctx, nodes, &S.nodes)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, aN, &S.attrN)) ||
+    repack_nodes(nodes);
+    if ((rc = upload(ctx, nodes, &S.nodes)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, aN, &S.attrN)) ||
         (rc = upload(ctx, aC, &S.attrC)) || (rc = upload(ctx, aE, &S.attrE)) || (rc = upload(ctx, light, &S.light))) {
         free_scene(ctx);
         return rc;
@@ -465,6 +494,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         std::vector<float4> sah;
         int n2 = 0;
         if (build_leaf_sah(sc, sah, &n2)) {
+            repack_nodes(sah);
             if ((rc = upload(ctx, sah, &ctx->nodes_sah))) { free_scene(ctx); return rc; }
             ctx->N_sah = n2;
         }
@@ -522,7 +552,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     if (k == "traversal" && value >= 0 && value <= 3) { ctx->opt_traversal = (int)value; ctx->prim_valid = false; }
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
-    else if (k == "pipeline" && (value == 0 || value == 1)) ctx->opt_pipeline = (int)value;
+    else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;
     else if (k == "frame_batch" && value >= 0 && value <= 4096) ctx->opt_frame_batch = (int)value;
     else if (k == "tasks_per_wave" && value >= 64 && value <= (1 << 20)) ctx->opt_tasks_per_wave = (int)value;
     else return fail(ctx, PTX_ERR_INVALID, "ptx_set_option: unknown key or bad value: " + k);
@@ -575,6 +605,16 @@ static void launch_render_wave(ptx_ctx* ctx, uint32_t nf) {
                        ctx->d_prim_tri, ctx->d_fb, nf, per_wave, ctx->d_counters);
 }
 
+template <bool PRUNE, bool MEMO, bool COUNT>
+static void launch_render_pool(ptx_ctx* ctx, uint32_t nf) {
+    const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
+    const uint64_t total = (uint64_t)tiles * 64u * nf;
+    const uint32_t per_wave = (uint32_t)ctx->opt_tasks_per_wave;
+    const uint32_t blocks = (uint32_t)((total + per_wave - 1) / per_wave);
+    hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
+                       ctx->d_prim_tri, ctx->d_fb, nf, per_wave, ctx->d_counters);
+}
+
 extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
     if (!ctx) return PTX_ERR_INVALID;
     if (!timestamps && n_frames) return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames: timestamps is NULL");
@@ -615,7 +655,18 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         const int sel = (opt_prune(ctx) ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
-        if (ctx->opt_pipeline == 1) {
+        if (ctx->opt_pipeline == 2) {
+            switch (sel) {
+                case 0: launch_render_pool<false, false, false>(ctx, nf); break;
+                case 1: launch_render_pool<false, false, true>(ctx, nf); break;
+                case 2: launch_render_pool<false, true, false>(ctx, nf); break;
+                case 3: launch_render_pool<false, true, true>(ctx, nf); break;
+                case 4: launch_render_pool<true, false, false>(ctx, nf); break;
+                case 5: launch_render_pool<true, false, true>(ctx, nf); break;
+                case 6: launch_render_pool<true, true, false>(ctx, nf); break;
+                default: launch_render_pool<true, true, true>(ctx, nf); break;
+            }
+        } else if (ctx->opt_pipeline == 1) {
             switch (sel) {
                 case 0: launch_render_wave<false, false, false>(ctx, nf); break;
                 case 1: launch_render_wave<false, false, true>(ctx, nf); break;

@@ -1,11 +1,15 @@
 // ptx_kernels.h -- device data layout + kernels of the progressive path tracer (gfx950).
 //
 // HBM layout (replaces the eleven RGB32F data textures of main.js:272-282; DESIGN.md "Data layout"):
-//   nodes[2N] float4: [2i]   = { min.xyz, bits(miss link) }
-//                     [2i+1] = { max.xyz, bits(leaf ? first | count << 24 : -2) }      (one 32-B record per node)
+//   nodes[2N] float4: [2i]   = { min.x, min.y, max.x, max.y }                            (one 32-B record per node; the
+//                     [2i+1] = { min.z, max.z, bits(miss link), bits(leaf ? first | count << 24 : -2) }   pairs feed v_pk_*_f32)
 //   tris[3T]  float4: [3k]   = { v0.xyz, bits(original triangle index) }  -- indexed by INORDER SLOT k, so a
 //                     [3k+1] = { (v1 - v0).xyz, 0 }                           leaf's triangles are contiguous
 //                     [3k+2] = { (v2 - v0).xyz, 0 }                           (one 48-B record per triangle)
+//   pairs[5T] float4: pair p of the leaf that starts at slot `first` is record first + p (80 B) and holds slots
+//                     first + 2p (A) and first + 2p + 1 (B, zeros when the leaf's count is odd), component-interleaved:
+//                     {v0x A,B, v0y A,B} {v0z A,B, e1x A,B} {e1y A,B, e1z A,B} {e2x A,B, e2y A,B}
+//                     {e2z A,B, bits(triangles of the leaf from this pair on), 0}        (pipeline 2 only)
 //   attrN/attrC/attrE[T] float4 { normal | color | emission } by ORIGINAL triangle index
 //   light[L]  6 x float4 { v0, v1, v2, normal, emission, {1/(L*area),0,0,0} }
 // One node visit = 32 B, one triangle test = 48 B, attributes (48 B) only for the winning hit.
@@ -17,6 +21,7 @@ namespace ptx {
 struct DScene {
     const float4* nodes;   // 2 float4 per node
     const float4* tris;    // 3 float4 per inorder slot
+    const float4* pairs;   // 5 float4 per triangle pair, indexed by first slot of the leaf + pair number
     const float4* attrN;
     const float4* attrC;
     const float4* attrE;
@@ -127,7 +132,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
             const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
             if (COUNT) c.node_visits++;
             float tn;
-            bool hit = slab_test(o, inv, mk(a), mk(b), tn);
+            bool hit = slab_node(o, inv, a, b, tn);
             if (PRUNE) hit = hit && !(tn > limit);
             if (hit) {
                 const int fc = __float_as_int(b.w);
@@ -138,7 +143,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
                 }
                 i++;
             } else {
-                i = (uint32_t)__float_as_int(a.w);
+                i = (uint32_t)__float_as_int(b.z);
             }
         }
         int j = 0;

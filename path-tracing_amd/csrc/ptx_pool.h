@@ -1,0 +1,249 @@
+// ptx_pool.h -- pipeline 2: wave-scheduled path tracer with a SHARED leaf queue (gfx950, wave64).
+//
+// Same idea as ptx_wave.h (every lane a persistent state machine, the wave votes which kind of work runs next), but the
+// triangle work is decoupled from the lane that found it.  A lane whose walk hits a leaf box appends an item
+// {first slot | owner lane, slab entry distance} to a queue in LDS that belongs to the whole wave.  The TRI phase hands
+// the 64 oldest items to the 64 lanes, whoever owns them: a lane fetches the owner's ray out of the owner's registers
+// (ds_bpermute), tests the leaf's triangles (glsl:150-173) and merges its best hit into the owner's 64-bit key
+// (t bits << 32 | inorder slot) with one LDS min -- the lexicographic (t, slot) minimum the reference's strict '<' in
+// increasing slot order produces.  So TRI phases run with every lane busy whenever the wave has 64 leaves pending, no
+// matter how unevenly the rays produced them, and the walk never stalls on a full per-lane queue.
+// With PRUNE an item is dropped when its leaf's entry distance is already behind the owner's best hit by the time it
+// is dequeued (same conservative margin as the node test; front-to-back order makes this frequent).
+// A ray is finished when its walk has ended and its pending-item count is back to zero.
+#pragma once
+#include "ptx_wave.h"
+
+#ifndef PTX_POOL_QCAP
+#define PTX_POOL_QCAP 128        // queue entries per wave (power of two, >= 128: one WALK step may add 64)
+#endif
+#ifndef PTX_POOL_WALK_STEPS
+#define PTX_POOL_WALK_STEPS 16   // node steps per WALK phase (ends early when the queue could overflow)
+#endif
+#ifndef PTX_POOL_SHADE_W
+#define PTX_POOL_SHADE_W 4       // a lane waiting for SHADE weighs this many QUARTERS of a walking lane / queued leaf in the vote
+#endif
+
+namespace ptx {
+
+#define PTX_POOL_KEY_NONE ((unsigned long long)0x7e967699u << 32 | 0xFFFFFFFFull)   // bits(1.0e38f) << 32 | 0xFFFFFFFF: "no hit yet"
+
+template <bool PRUNE, bool MEMO, bool COUNT>
+__global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
+                                                    const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
+                                                    float4* __restrict__ fb, uint32_t n_frames, uint32_t tasks_per_wave,
+                                                    unsigned long long* counters) {
+    __shared__ float lds[PW_WORDS * 64];
+    __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
+    __shared__ uint32_t pend[64];                    // leaf items of the lane's ray still in the queue
+    __shared__ uint2 queue[PTX_POOL_QCAP];
+    const uint32_t lane = threadIdx.x;
+    const LdsLane L{lds + lane};
+    const uint32_t npix = P.W * P.H;
+    const uint32_t tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
+    const uint32_t tasks_per_frame = tiles_x * tiles_y * 64u;          // padded to whole 8x8 tiles
+    const uint32_t total = tasks_per_frame * n_frames;                 // host guarantees < 2^32
+    uint32_t next = blockIdx.x * tasks_per_wave;                       // wave-uniform cursor into the task list
+    const uint32_t last = (total - next > tasks_per_wave) ? next + tasks_per_wave : total;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+#pragma unroll
+    for (int w = PW_C_SAMPLES; w <= PW_C_PF; w++) L.sti(w, 0);
+    keys[lane] = PTX_POOL_KEY_NONE;
+    pend[lane] = 0;
+    unsigned long long cyc[3] = {0, 0, 0}, its[3] = {0, 0, 0};
+    uint32_t cnt_nodes = 0, cnt_tris = 0, d_walk = 0, d_tri = 0, d_shade = 0, d_walk_s = 0, d_tri_s = 0, d_shade_s = 0;   // COUNT only
+
+    int flags = F_ALIVE;
+    V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f), inv = mk(0.f, 0.f, 0.f);
+    float limit = 3.0e38f;
+    uint32_t i = 0xFFFFFFFFu, nbase = 0;
+    const uint32_t N = (uint32_t)S.N;
+    const float4* nodes_hi = S.nodes + 1;            // second half of a node record through its own base: no offset add
+    uint32_t head = 0, tail = 0;                     // wave-uniform queue cursors (free running)
+
+    for (;;) {
+        const bool trav = (flags & F_TRAV) != 0;
+        const bool walking = trav && i < N;
+        const bool need_shade = (flags & F_ALIVE) && !(trav && (i < N || pend[lane] != 0));
+        const int nW = __popcll(__ballot(walking)), nS = __popcll(__ballot(need_shade));
+        const uint32_t len = tail - head;
+        if ((nW | nS) == 0 && len == 0) break;
+        int phase;   // 0 walk, 1 tri, 2 shade
+        if (len >= 64u) phase = 1;
+        else {
+            const int sw = nW, st = (int)len, ss = (nS * PTX_POOL_SHADE_W) >> 2;
+            if (nS > 0 && ss >= sw && ss >= st) phase = 2;
+            else if (nW > 0 && sw >= st) phase = 0;
+            else phase = 1;
+        }
+        phase = __builtin_amdgcn_readfirstlane(phase);
+        unsigned long long t_ph = 0;
+        if (COUNT) t_ph = __builtin_amdgcn_s_memtime();
+
+        if (phase == 0) {
+            if (PRUNE) limit = __uint_as_float((uint32_t)(keys[lane] >> 32)) * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+#pragma nounroll
+            for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
+                if (tail - head > (uint32_t)(PTX_POOL_QCAP - 64)) break;
+                const bool w = trav && i < N;
+                bool push = false;
+                uint32_t item = 0;
+                float tn = 0.f;
+                if (w) {
+                    const float4 a = ld16(S.nodes, nbase + (i << 5));
+                    const float4 b = ld16(nodes_hi, nbase + (i << 5));
+                    int miss = __float_as_int(b.z), fc = __float_as_int(b.w);
+                    asm volatile("" : "+v"(miss), "+v"(fc));     // keep the links in the record's two loads (no third, dependent one)
+                    if (COUNT) cnt_nodes++;
+                    bool hit = slab_node(ro, inv, a, b, tn);
+                    if (PRUNE) hit = hit && !(tn > limit);
+                    push = hit && fc != -2 && (fc >> 24) != 0;       // internal nodes and empty leaves queue nothing
+                    item = ((uint32_t)fc & 0x00FFFFFFu) | (lane << 24);
+                    i = hit ? i + 1u : (uint32_t)miss;
+                }
+                const unsigned long long m = __ballot(push);
+                if (push) {
+                    queue[(tail + (uint32_t)__popcll(m & lt_mask)) & (PTX_POOL_QCAP - 1)] = make_uint2(item, __float_as_uint(tn));
+                    atomicAdd(&pend[lane], 1u);
+                }
+                tail += (uint32_t)__popcll(m);
+                if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
+                if (__ballot(trav && i < N) == 0ull) break;
+            }
+        } else if (phase == 1) {
+            const uint32_t n = min(len, 64u);
+            const bool has = lane < n;
+            const uint2 it = queue[(head + lane) & (PTX_POOL_QCAP - 1)];
+            head += n;
+            const uint32_t owner = has ? ((it.x >> 24) & 63u) : lane;
+            const uint32_t first = it.x & 0x00FFFFFFu;
+            // the owner's ray, straight out of the owner's registers (every lane executes the shuffles)
+            const V3 o = mk(__shfl(ro.x, (int)owner), __shfl(ro.y, (int)owner), __shfl(ro.z, (int)owner));
+            const V3 d = mk(__shfl(rd.x, (int)owner), __shfl(rd.y, (int)owner), __shfl(rd.z, (int)owner));
+            bool go = has;
+            if (PRUNE) {
+                const float b = __uint_as_float((uint32_t)(keys[owner] >> 32));
+                go = go && !(__uint_as_float(it.y) > b * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS);
+            }
+            float bt = 1.0e38f;
+            uint32_t bk = 0xFFFFFFFFu;
+            uint32_t k = first;                               // slot of triangle A of the pair; the pair record is pairs[k0 + round]
+            uint32_t pbyte = first * 80u;
+            bool more = go;
+            while (__ballot(more) != 0ull) {
+                if (COUNT) { d_tri += more ? 1u : 0u; if (lane == 0) d_tri_s += 64u; }
+                if (more) {
+                    const float4 r0 = ld16(S.pairs, pbyte), r1 = ld16(S.pairs, pbyte + 16u), r2 = ld16(S.pairs, pbyte + 32u),
+                                 r3 = ld16(S.pairs, pbyte + 48u), r4 = ld16(S.pairs, pbyte + 64u);
+                    const int rem = __float_as_int(r4.z);      // triangles of the leaf from this pair on (>= 1)
+                    bool hA, hB;
+                    float tA, tB;
+                    tri_test2(o, d, r0, r1, r2, r3, r4, hA, hB, tA, tB);
+                    if (COUNT) cnt_tris += rem >= 2 ? 2u : 1u;
+                    if (hA && tA < bt) { bt = tA; bk = k; }
+                    if (hB && tB < bt) { bt = tB; bk = k + 1u; }
+                    more = rem > 2;
+                    k += 2u;
+                    pbyte += 80u;
+                }
+            }
+            if (bt < 1.0e38f) atomicMin(&keys[owner], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)bk);
+            if (has) atomicSub(&pend[owner], 1u);
+        } else {
+            if (COUNT) { d_shade += need_shade ? 1u : 0u; if (lane == 0) d_shade_s += 64u; }
+            bool run_shade = need_shade && (flags & F_TASK);      // a finished ray (or a pending cached primary hit)
+            bool want_task = need_shade && !(flags & F_TASK);
+            bool start_trav = false;
+            LocalCnt c = {};
+            PathLds p{L, ro, rd, P, prim_t, prim_tri};
+            // (1) hand out the wave's next tasks (wave-uniform control flow: the cursor `next` stays uniform)
+            for (;;) {
+                const unsigned long long m = __ballot(want_task);
+                if (m == 0) break;
+                const uint32_t mine = next + (uint32_t)__popcll(m & lt_mask);
+                const uint32_t avail = last - next;
+                next += min((uint32_t)__popcll(m), avail);
+                if (want_task) {
+                    if (mine >= last) {
+                        flags = 0; want_task = false;
+                    } else {
+                        const uint32_t frame = mine / tasks_per_frame;
+                        const uint32_t r = mine - frame * tasks_per_frame;
+                        uint32_t px, py;
+                        if (tile_pixel(P, r >> 6, r & 63u, px, py)) {      // else: padding lane of an edge tile, draw again
+                            const uint32_t pix = py * P.W + px;
+                            L.sti(PW_PIX, (int)pix); L.sti(PW_FRAME, (int)frame); L.sti(PW_PACK, 0);
+                            const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], 0.f, 0, c);
+                            if (st == SH_DONE) {                            // max_path_length <= 0: black; draw again
+                                fb[(size_t)frame * npix + pix] = make_float4(0.f, 0.f, 0.f, 1.0f);
+                                L.sti(PW_C_PF, L.ldi(PW_C_PF) + 1);
+                            } else {
+                                flags |= F_TASK;
+                                want_task = false;
+                                if (st == SH_CACHED) { flags |= F_CACHED; run_shade = true; }
+                                else { flags &= ~F_CACHED; start_trav = true; }
+                            }
+                        }
+                    }
+                }
+            }
+            // (2) consume finished rays / cached primary hits
+            if (run_shade) {
+                const unsigned long long key = keys[lane];
+                float t = __uint_as_float((uint32_t)(key >> 32));
+                bool hit = t < 1.0e38f;
+                int tri = -1;
+                bool cached = (flags & F_CACHED) != 0;
+                if (hit && !cached) tri = __float_as_int(ld16(S.tris, (uint32_t)key * 48u).w);
+                int st;
+                for (;;) {
+                    if (cached) { t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri(); }
+                    st = shade_step<MEMO>(S, P, p, hit, t, tri, c);
+                    cached = (st == SH_CACHED);
+                    if (st != SH_CACHED) break;
+                }
+                flags &= ~F_CACHED;
+                if (st == SH_DONE) {
+                    const V3 rgb = path_result(P, p);
+                    fb[(size_t)(uint32_t)L.ldi(PW_FRAME) * npix + (uint32_t)L.ldi(PW_PIX)] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+                    L.sti(PW_C_PF, L.ldi(PW_C_PF) + 1);
+                    flags &= ~(F_TASK | F_TRAV);          // takes its next task in the next SHADE phase
+                } else {
+                    start_trav = true;
+                }
+            }
+            // (3) start the traversal of the lanes that now hold a fresh ray
+            if (start_trav) {
+                inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                nbase = octant(rd) * S.oct_stride;
+                keys[lane] = PTX_POOL_KEY_NONE;
+                limit = 3.0e38f;
+                i = 0;
+                flags |= F_TRAV;
+                c.rays_traced++;
+            }
+            if (need_shade) {
+                L.sti(PW_C_SAMPLES, L.ldi(PW_C_SAMPLES) + (int)c.samples); L.sti(PW_C_RAYS, L.ldi(PW_C_RAYS) + (int)c.rays);
+                L.sti(PW_C_TRACED, L.ldi(PW_C_TRACED) + (int)c.rays_traced); L.sti(PW_C_HITS, L.ldi(PW_C_HITS) + (int)c.ray_hits);
+                L.sti(PW_C_ATT, L.ldi(PW_C_ATT) + (int)c.light_attempts);
+            }
+        }
+        if (COUNT) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_ph;
+            if (lane == 0) { cyc[phase] += dt; its[phase]++; }
+        }
+    }
+    if (COUNT && lane == 0) {
+        for (int e = 0; e < 3; e++) { atomicAdd(&counters[CNT_CYC_WALK + e], cyc[e]); atomicAdd(&counters[CNT_IT_WALK + e], its[e]); }
+    }
+    LocalCnt c = {};
+    c.samples = (uint32_t)L.ldi(PW_C_SAMPLES); c.rays = (uint32_t)L.ldi(PW_C_RAYS); c.rays_traced = (uint32_t)L.ldi(PW_C_TRACED);
+    c.ray_hits = (uint32_t)L.ldi(PW_C_HITS); c.light_attempts = (uint32_t)L.ldi(PW_C_ATT);
+    c.node_visits = cnt_nodes; c.tri_tests = cnt_tris;
+    c.walk_useful = d_walk; c.walk_slots = d_walk_s; c.tri_useful = d_tri; c.tri_slots = d_tri_s; c.trace_useful = d_shade; c.trace_slots = d_shade_s;
+    flush_counters(c, counters, (uint32_t)L.ldi(PW_C_PF));
+}
+
+} // namespace ptx

@@ -167,14 +167,14 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                     const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
                     if (COUNT) cnt_nodes++;
                     float tn;
-                    bool hit = slab_test(ro, inv, mk(a), mk(b), tn);
+                    bool hit = slab_node(ro, inv, a, b, tn);
                     if (PRUNE) hit = hit && !(tn > limit);
                     const int fc = __float_as_int(b.w);
                     const bool push = hit && fc != -2;
 #pragma unroll
                     for (int e = 0; e < PTX_WAVE_QUEUE; e++) if (push && e == nq) q[e] = fc;
                     nq += push ? 1 : 0;
-                    i = hit ? i + 1u : (uint32_t)__float_as_int(a.w);
+                    i = hit ? i + 1u : (uint32_t)__float_as_int(b.z);
                 }
             }
             if (PTX_WAVE_WALK_KEEP && __popcll(__ballot(trav && i < N && nq < PTX_WAVE_QUEUE)) < keepW) break;

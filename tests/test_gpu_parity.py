@@ -22,7 +22,7 @@ def setup(ctx, ptx, name, w, h, spp=4, bounces=4, **opts):
     p = ptx.config_params(name, w, h, spp, bounces)
     ctx.upload_scene(s)
     ctx.set_params(p)
-    for k, v in {**dict(traversal=3, memo=1, count=0, frame_batch=0, pipeline=1, tasks_per_wave=128), **opts}.items():
+    for k, v in {**dict(traversal=3, memo=1, count=0, frame_batch=0, pipeline=2, tasks_per_wave=128), **opts}.items():
         ctx.set_option(k, v)
     ctx.reset_accum()
     ctx.reset_counters()
@@ -87,7 +87,8 @@ def test_trace_closest_empty_and_single(gpu_ctx, ptx, orc):
 @pytest.mark.parametrize("name,size,spp,bounces", [("cornell", (48, 48), 4, 4), ("my_cornell_6", (64, 64), 4, 5), ("bedroom2_v5", (64, 36), 3, 4),
                                                    ("teapot", (64, 36), 3, 4), ("pixar_room", (96, 54), 4, 8), ("pixar_room", (27, 45), 2, 12)])
 @pytest.mark.parametrize("traversal,memo,pipeline", [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (2, 1, 0), (3, 1, 0),
-                                                     (0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1), (2, 0, 1), (3, 1, 1)])
+                                                     (0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1), (2, 0, 1), (3, 1, 1),
+                                                     (0, 0, 2), (0, 1, 2), (1, 0, 2), (1, 1, 2), (2, 0, 2), (3, 1, 2)])
 def test_frames_bit_exact_and_counters(gpu_ctx, ptx, orc, name, size, spp, bounces, traversal, memo, pipeline):
     s, p = setup(gpu_ctx, ptx, name, *size, spp=spp, bounces=bounces, traversal=traversal, memo=memo, count=1, pipeline=pipeline)
     ts = ptx.scene.timestamps(3)
@@ -229,6 +230,12 @@ def test_full_size_properties(gpu_ctx, ptx, orc, cfg):
     gpu_ctx.set_option("traversal", 0); gpu_ctx.set_option("memo", 0); gpu_ctx.set_option("pipeline", 0)
     gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); lit = gpu_ctx.read_sum()
     gpu_ctx.set_option("traversal", 2); gpu_ctx.set_option("memo", 1); gpu_ctx.set_option("pipeline", 1)
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); sah = gpu_ctx.read_sum()
+    assert (bits(lit) == bits(sah)).all()
+    gpu_ctx.set_option("traversal", 3)
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); w3 = gpu_ctx.read_sum()
+    assert (bits(lit) == bits(w3)).all()
+    gpu_ctx.set_option("traversal", 2); gpu_ctx.set_option("pipeline", 2)              # the default pipeline (shared leaf queue)
     gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:1]); sah = gpu_ctx.read_sum()
     assert (bits(lit) == bits(sah)).all()
     gpu_ctx.set_option("traversal", 3)

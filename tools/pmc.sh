@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export PERF_TRAV=3 PERF_FRAMES=4
+export PERF_TRAV=${PERF_TRAV:-3} PERF_FRAMES=${PERF_FRAMES:-4}
 i=0
 for PMC in "$@"; do
   i=$((i+1))
