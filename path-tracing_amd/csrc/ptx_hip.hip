@@ -517,7 +517,7 @@ extern "C" int ptx_reset_accum(ptx_ctx* ctx) {
 extern "C" int ptx_set_params(ptx_ctx* ctx, const ptx_params* p) {
     if (!ctx) return PTX_ERR_INVALID;
     if (!p) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: params is NULL");
-    if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height > (1ull << 28)) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: bad image size");
+    if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height > (1ull << 26)) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: bad image size (width * height must be in 1 .. 2^26)");
     if (p->sample_count < 1) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: sample_count must be >= 1");
     if (p->max_path_length > 65535) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: max_path_length must be <= 65535");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -629,6 +629,7 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
     // frames rendered concurrently: bounded by an 8 GiB frame-buffer budget (HBM is 288 GB) and 65535 grid.y
     size_t batch = ctx->opt_frame_batch > 0 ? (size_t)ctx->opt_frame_batch : std::min<size_t>(64, std::max<size_t>(1, (8ull << 30) / (npix * sizeof(float4))));
     batch = std::min<size_t>(batch, n_frames);
+    if (ctx->opt_pipeline != 0) batch = std::min<size_t>(batch, 64);   // pipelines 1 and 2 keep the frame-in-batch in 6 bits
     {   // pipeline 1 indexes (pixel, frame) tasks with 32 bits
         const uint64_t padded = (uint64_t)((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8) * 64u;
         batch = std::max<size_t>(1, std::min<size_t>(batch, (size_t)(0xF0000000ull / padded)));

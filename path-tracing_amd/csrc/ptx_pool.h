@@ -10,7 +10,7 @@
 // matter how unevenly the rays produced them, and the walk never stalls on a full per-lane queue.
 // With PRUNE an item is dropped when its leaf's entry distance is already behind the owner's best hit by the time it
 // is dequeued (same conservative margin as the node test; front-to-back order makes this frequent).
-// A ray is finished when its walk has ended and its pending-item count is back to zero.
+// A ray is finished when its walk has ended and the queue head has passed its newest item (items are consumed in order).
 #pragma once
 #include "ptx_wave.h"
 
@@ -24,18 +24,21 @@
 #define PTX_POOL_SHADE_W 4       // a lane waiting for SHADE weighs this many QUARTERS of a walking lane / queued leaf in the vote
 #endif
 
+#ifndef PTX_POOL_MIN_WAVES
+#define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
+#endif
+
 namespace ptx {
 
 #define PTX_POOL_KEY_NONE ((unsigned long long)0x7e967699u << 32 | 0xFFFFFFFFull)   // bits(1.0e38f) << 32 | 0xFFFFFFFF: "no hit yet"
 
 template <bool PRUNE, bool MEMO, bool COUNT>
-__global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
+__global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
                                                     const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
                                                     float4* __restrict__ fb, uint32_t n_frames, uint32_t tasks_per_wave,
                                                     unsigned long long* counters) {
-    __shared__ float lds[PW_WORDS * 64];
+    __shared__ float lds[PW_C_SAMPLES * 64];         // path state only: the work counters are wave totals in wcnt[]
     __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
-    __shared__ uint32_t pend[64];                    // leaf items of the lane's ray still in the queue
     __shared__ uint2 queue[PTX_POOL_QCAP];
     const uint32_t lane = threadIdx.x;
     const LdsLane L{lds + lane};
@@ -47,10 +50,7 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
     const uint32_t last = (total - next > tasks_per_wave) ? next + tasks_per_wave : total;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-#pragma unroll
-    for (int w = PW_C_SAMPLES; w <= PW_C_PF; w++) L.sti(w, 0);
     keys[lane] = PTX_POOL_KEY_NONE;
-    pend[lane] = 0;
     unsigned long long cyc[3] = {0, 0, 0}, its[3] = {0, 0, 0};
     uint32_t cnt_nodes = 0, cnt_tris = 0, d_walk = 0, d_tri = 0, d_shade = 0, d_walk_s = 0, d_tri_s = 0, d_shade_s = 0;   // COUNT only
 
@@ -61,11 +61,15 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
     const uint32_t N = (uint32_t)S.N;
     const float4* nodes_hi = S.nodes + 1;            // second half of a node record through its own base: no offset add
     uint32_t head = 0, tail = 0;                     // wave-uniform queue cursors (free running)
+    // work counters as wave totals in scalar registers: every increment is a ballot + popcount in wave-uniform control flow
+    uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
+    uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
+                                                     // been tested once head has passed it (items are consumed in order)
 
     for (;;) {
         const bool trav = (flags & F_TRAV) != 0;
         const bool walking = trav && i < N;
-        const bool need_shade = (flags & F_ALIVE) && !(trav && (i < N || pend[lane] != 0));
+        const bool need_shade = (flags & F_ALIVE) && !(trav && (i < N || (int32_t)(head - lastpos) < 0));
         const int nW = __popcll(__ballot(walking)), nS = __popcll(__ballot(need_shade));
         const uint32_t len = tail - head;
         if ((nW | nS) == 0 && len == 0) break;
@@ -104,8 +108,9 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
                 }
                 const unsigned long long m = __ballot(push);
                 if (push) {
-                    queue[(tail + (uint32_t)__popcll(m & lt_mask)) & (PTX_POOL_QCAP - 1)] = make_uint2(item, __float_as_uint(tn));
-                    atomicAdd(&pend[lane], 1u);
+                    const uint32_t pos = tail + (uint32_t)__popcll(m & lt_mask);
+                    queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(item, __float_as_uint(tn));
+                    lastpos = pos + 1u;
                 }
                 tail += (uint32_t)__popcll(m);
                 if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
@@ -149,13 +154,11 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
                 }
             }
             if (bt < 1.0e38f) atomicMin(&keys[owner], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)bk);
-            if (has) atomicSub(&pend[owner], 1u);
         } else {
             if (COUNT) { d_shade += need_shade ? 1u : 0u; if (lane == 0) d_shade_s += 64u; }
             bool run_shade = need_shade && (flags & F_TASK);      // a finished ray (or a pending cached primary hit)
             bool want_task = need_shade && !(flags & F_TASK);
             bool start_trav = false;
-            LocalCnt c = {};
             PathLds p{L, ro, rd, P, prim_t, prim_tri};
             // (1) hand out the wave's next tasks (wave-uniform control flow: the cursor `next` stays uniform)
             for (;;) {
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
                 const uint32_t mine = next + (uint32_t)__popcll(m & lt_mask);
                 const uint32_t avail = last - next;
                 next += min((uint32_t)__popcll(m), avail);
+                bool black = false;
                 if (want_task) {
                     if (mine >= last) {
                         flags = 0; want_task = false;
@@ -173,11 +177,12 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
                         uint32_t px, py;
                         if (tile_pixel(P, r >> 6, r & 63u, px, py)) {      // else: padding lane of an edge tile, draw again
                             const uint32_t pix = py * P.W + px;
-                            L.sti(PW_PIX, (int)pix); L.sti(PW_FRAME, (int)frame); L.sti(PW_PACK, 0);
-                            const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], 0.f, 0, c);
+                            L.sti(PW_PIX, (int)(pix | (frame << 26))); L.sti(PW_PACK, 0);
+                            LocalCnt cb = {};
+                            const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], 0.f, 0, cb);
                             if (st == SH_DONE) {                            // max_path_length <= 0: black; draw again
                                 fb[(size_t)frame * npix + pix] = make_float4(0.f, 0.f, 0.f, 1.0f);
-                                L.sti(PW_C_PF, L.ldi(PW_C_PF) + 1);
+                                black = true;
                             } else {
                                 flags |= F_TASK;
                                 want_task = false;
@@ -187,31 +192,49 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
                         }
                     }
                 }
+                w_pf += (uint32_t)__popcll(__ballot(black));
             }
-            // (2) consume finished rays / cached primary hits
-            if (run_shade) {
-                const unsigned long long key = keys[lane];
-                float t = __uint_as_float((uint32_t)(key >> 32));
-                bool hit = t < 1.0e38f;
+            // (2) consume finished rays / cached primary hits.  A lane may go through several samples in a row (primary ray
+            //     misses or hits an emitter: every sample ends at once); the loop is wave-uniform so the counters stay scalar
+            {
+                float t = 0.f;
+                bool hit = false;
                 int tri = -1;
                 bool cached = (flags & F_CACHED) != 0;
-                if (hit && !cached) tri = __float_as_int(ld16(S.tris, (uint32_t)key * 48u).w);
-                int st;
-                for (;;) {
-                    if (cached) { t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri(); }
-                    st = shade_step<MEMO>(S, P, p, hit, t, tri, c);
-                    cached = (st == SH_CACHED);
-                    if (st != SH_CACHED) break;
+                if (run_shade && !cached) {
+                    const unsigned long long key = keys[lane];
+                    t = __uint_as_float((uint32_t)(key >> 32));
+                    hit = t < 1.0e38f;
+                    if (hit) tri = __float_as_int(ld16(S.tris, (uint32_t)key * 48u).w);
                 }
-                flags &= ~F_CACHED;
-                if (st == SH_DONE) {
-                    const V3 rgb = path_result(P, p);
-                    fb[(size_t)(uint32_t)L.ldi(PW_FRAME) * npix + (uint32_t)L.ldi(PW_PIX)] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
-                    L.sti(PW_C_PF, L.ldi(PW_C_PF) + 1);
-                    flags &= ~(F_TASK | F_TRAV);          // takes its next task in the next SHADE phase
-                } else {
-                    start_trav = true;
+                bool act = run_shade;
+                int st = SH_TRACE;
+                while (__ballot(act) != 0ull) {
+                    LocalCnt cc = {};
+                    if (act) {
+                        if (cached) { t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri(); }
+                        st = shade_step<MEMO>(S, P, p, hit, t, tri, cc);
+                        cached = (st == SH_CACHED);
+                        act = cached;
+                    }
+                    // per call: rays 1 or 2 (the memoised shadow ray), hits 0..2, light attempts 0 or 1
+                    w_rays += (uint32_t)__popcll(__ballot(cc.rays >= 1u)) + (uint32_t)__popcll(__ballot(cc.rays >= 2u));
+                    w_hits += (uint32_t)__popcll(__ballot(cc.ray_hits >= 1u)) + (uint32_t)__popcll(__ballot(cc.ray_hits >= 2u));
+                    w_att += (uint32_t)__popcll(__ballot(cc.light_attempts >= 1u));
                 }
+                bool done = false;
+                if (run_shade) {
+                    flags &= ~F_CACHED;
+                    if (st == SH_DONE) {
+                        const V3 rgb = path_result(P, p);
+                        fb[(size_t)p.frame() * npix + p.pix()] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+                        done = true;
+                        flags &= ~(F_TASK | F_TRAV);          // takes its next task in the next SHADE phase
+                    } else {
+                        start_trav = true;
+                    }
+                }
+                w_pf += (uint32_t)__popcll(__ballot(done));
             }
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
@@ -220,14 +243,10 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
                 keys[lane] = PTX_POOL_KEY_NONE;
                 limit = 3.0e38f;
                 i = 0;
+                lastpos = head;
                 flags |= F_TRAV;
-                c.rays_traced++;
             }
-            if (need_shade) {
-                L.sti(PW_C_SAMPLES, L.ldi(PW_C_SAMPLES) + (int)c.samples); L.sti(PW_C_RAYS, L.ldi(PW_C_RAYS) + (int)c.rays);
-                L.sti(PW_C_TRACED, L.ldi(PW_C_TRACED) + (int)c.rays_traced); L.sti(PW_C_HITS, L.ldi(PW_C_HITS) + (int)c.ray_hits);
-                L.sti(PW_C_ATT, L.ldi(PW_C_ATT) + (int)c.light_attempts);
-            }
+            w_traced += (uint32_t)__popcll(__ballot(start_trav));
         }
         if (COUNT) {
             __builtin_amdgcn_s_waitcnt(0);
@@ -239,11 +258,12 @@ __global__ __launch_bounds__(64) void k_render_pool(DScene S, DParams P, const i
         for (int e = 0; e < 3; e++) { atomicAdd(&counters[CNT_CYC_WALK + e], cyc[e]); atomicAdd(&counters[CNT_IT_WALK + e], its[e]); }
     }
     LocalCnt c = {};
-    c.samples = (uint32_t)L.ldi(PW_C_SAMPLES); c.rays = (uint32_t)L.ldi(PW_C_RAYS); c.rays_traced = (uint32_t)L.ldi(PW_C_TRACED);
-    c.ray_hits = (uint32_t)L.ldi(PW_C_HITS); c.light_attempts = (uint32_t)L.ldi(PW_C_ATT);
+    if (lane == 0) {   // every task runs exactly spp samples (glsl:521-525), so samples = pixel-frames x spp
+        c.samples = w_pf * (uint32_t)P.spp; c.rays = w_rays; c.rays_traced = w_traced; c.ray_hits = w_hits; c.light_attempts = w_att;
+    }
     c.node_visits = cnt_nodes; c.tri_tests = cnt_tris;
     c.walk_useful = d_walk; c.walk_slots = d_walk_s; c.tri_useful = d_tri; c.tri_slots = d_tri_s; c.trace_useful = d_shade; c.trace_slots = d_shade_s;
-    flush_counters(c, counters, (uint32_t)L.ldi(PW_C_PF));
+    flush_counters(c, counters, lane == 0 ? w_pf : 0u);
 }
 
 } // namespace ptx

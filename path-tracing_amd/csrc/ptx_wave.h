@@ -55,7 +55,7 @@ namespace ptx {
 //      registers, which keeps the hot loop small (few loop-carried registers, higher occupancy).
 // o and d are the lane's ray registers; dprim / prim_t / prim_tri are recomputed / reloaded from the pixel index.
 enum { PW_SX = 0, PW_SY, PW_SUM, PW_S = PW_SUM + 3, PW_THR, PW_RAD = PW_THR + 3, PW_N = PW_RAD + 3, PW_COL = PW_N + 3, PW_LP = PW_COL + 3,
-       PW_LPDF = PW_LP + 3, PW_LI, PW_PACK /* attempts | stage << 8 | bounce << 16 */, PW_PIX, PW_FRAME,
+       PW_LPDF = PW_LP + 3, PW_LI, PW_PACK /* attempts | stage << 8 | bounce << 16 */, PW_PIX /* pixel | frame-in-batch << 26 */,
        PW_C_SAMPLES, PW_C_RAYS, PW_C_TRACED, PW_C_HITS, PW_C_ATT, PW_C_PF, PW_WORDS };
 
 struct LdsLane {
@@ -88,7 +88,8 @@ struct PathLds {
     __device__ __forceinline__ void set_o(V3 v) const { ro = v; }
     __device__ __forceinline__ V3 d() const { return rd; }
     __device__ __forceinline__ void set_d(V3 v) const { rd = v; }
-    __device__ __forceinline__ uint32_t pix() const { return (uint32_t)L.ldi(PW_PIX); }
+    __device__ __forceinline__ uint32_t pix() const { return (uint32_t)L.ldi(PW_PIX) & 0x03FFFFFFu; }
+    __device__ __forceinline__ uint32_t frame() const { return (uint32_t)L.ldi(PW_PIX) >> 26; }
     __device__ __forceinline__ V3 dprim() const { const uint32_t px = pix(); return primary_dir(P, px % P.W, px / P.W); }
     __device__ __forceinline__ void set_dprim(V3) const {}
     __device__ __forceinline__ float prim_t() const { return prim_t_[pix()]; }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                         uint32_t px, py;
                         if (tile_pixel(P, r >> 6, r & 63u, px, py)) {      // else: padding lane of an edge tile, draw again
                             const uint32_t pix = py * P.W + px;
-                            L.sti(PW_PIX, (int)pix); L.sti(PW_FRAME, (int)frame); L.sti(PW_PACK, 0);
+                            L.sti(PW_PIX, (int)(pix | (frame << 26))); L.sti(PW_PACK, 0);
                             const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], 0.f, 0, c);
                             if (st == SH_DONE) {                            // max_path_length <= 0: black; draw again
                                 fb[(size_t)frame * npix + pix] = make_float4(0.f, 0.f, 0.f, 1.0f);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                 flags &= ~F_CACHED;
                 if (st == SH_DONE) {
                     const V3 rgb = path_result(P, p);
-                    fb[(size_t)(uint32_t)L.ldi(PW_FRAME) * npix + (uint32_t)L.ldi(PW_PIX)] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+                    fb[(size_t)p.frame() * npix + p.pix()] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
                     L.sti(PW_C_PF, L.ldi(PW_C_PF) + 1);
                     flags &= ~(F_TASK | F_TRAV);          // takes its next task in the next SHADE phase
                 } else {
