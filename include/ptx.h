@@ -112,6 +112,9 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *   "pipeline"  : 0 = one lane per (pixel, frame), rays traced one at a time; 1 = wave-scheduled, per-lane leaf queues:
  *                 per-lane walk / triangle / shade work voted per wave, persistent lanes drawing tasks (ptx_wave.h);
  *                 2 = wave-scheduled with one leaf queue per wave shared by its lanes (ptx_pool.h; default)
+ *   "compat_rgba8": 1 = also keep the reference's own progressive result: every frame is blended into an RGBA8 target
+ *                 exactly as glsl:532-552 + modules/bufferManager.js:18 do (8-bit rounding per frame, the aspect-shifted
+ *                 read of the previous target included); read it with ptx_read_compat_rgba8.  0 = off (default)
  *   "frame_batch": max frames rendered concurrently (0 = auto)
  *   "tasks_per_wave": (pixel, frame) tasks one wave of pipeline 1 / 2 works through (default 128)
  */
@@ -122,8 +125,8 @@ int ptx_set_option(ptx_ctx *ctx, const char *key, int64_t value);
  * frames: frame f runs sample_count paths per pixel seeded with timestamps[f] (uniform timestamp,
  * main.js:300; glsl:520) and adds clamp(mean, 0, 1) (glsl:526-529) to the float accumulation buffer, in
  * frame order.  first_frame_number mirrors uniform frameNumber (main.js:303) and is only book-keeping
- * here: the running mean sum/frames_done equals the reference's mix(prev, cur, 1/(frameNumber+1)) chain
- * (glsl:537-540) without its RGBA8 rounding.  Asynchronous: work is queued on the context's stream. */
+ * for the float accumulation: the running mean sum/frames_done equals the reference's mix(prev, cur, 1/(frameNumber+1))
+ * chain (glsl:537-540) without its RGBA8 rounding; with option "compat_rgba8" it is the frameNumber of that chain.  Asynchronous: work is queued on the context's stream. */
 int ptx_render_frames(ptx_ctx *ctx, const int32_t *timestamps, uint32_t n_frames, uint32_t first_frame_number);
 int ptx_synchronize(ptx_ctx *ctx);
 /* Replaces gl.clear of the ping-pong targets (main.js:326-327) / starting a new progressive render. */
@@ -138,6 +141,13 @@ int ptx_read_sum_f32(ptx_ctx *ctx, float *rgb);
 /* out: W*H*4 bytes. apply_gamma: pow(c, 1/2.2) as shaders/fragmentShaderOutput.glsl:35; flip_y: the
  * vertical flip of main.js:464-473 (row 0 = top row). Quantisation: floor(c*255 + 0.5). */
 int ptx_read_rgba8(ptx_ctx *ctx, uint8_t *out, int apply_gamma, int flip_y);
+
+/* The reference's RGBA8 ping-pong target after the last frame (option "compat_rgba8" = 1): what gl.readPixels (main.js:459)
+ * returns in the browser, for frame-by-frame comparison with captures.  apply_gamma / flip_y as ptx_read_rgba8. */
+int ptx_read_compat_rgba8(ptx_ctx *ctx, uint8_t *out, int apply_gamma, int flip_y);
+/* Checkpoint restore (new): sets the accumulation to rgb (W*H*3 floats as written by ptx_read_sum_f32) and
+ * the frame count to frames_done, so a long progressive render (main.js:391-436 renderAsync) can resume after a restart. */
+int ptx_write_sum_f32(ptx_ctx *ctx, const float *rgb, uint32_t frames_done);
 
 /* ---- parity / roofline hooks (new) ---- */
 /* Closest hit of n rays (o, d: 3n floats) by ray_bvh_intersection_hit_miss (glsl:207-249). A miss gives

@@ -34,6 +34,11 @@ CASES = {
     "pixar_room_b1": ("pixar_room", 48, 27, 4, 1, [1000]),
     "pixar_room_b8": ("pixar_room", 96, 54, 16, 8, [1000]),      # reduced headline (BASELINE.md plan 1)
     "my_cornell_6_tall_b1": ("my_cornell_6", 24, 40, 4, 1, [1000]),
+    # progressive: frameNumber = f, frames blended through the two RGBA8 targets (glsl:532-552); wide and tall images
+    # exercise the aspect-shifted read of the previous target
+    "my_cornell_6_prog_b1": ("my_cornell_6", 48, 48, 4, 1, [1000, 1001, 1002, 1003, 1004]),
+    "pixar_room_prog_b1": ("pixar_room", 48, 27, 4, 1, [1000, 1001, 1002, 1003]),
+    "my_cornell_6_tall_prog_b1": ("my_cornell_6", 24, 40, 4, 1, [1000, 1001, 1002, 1003]),
 }
 
 
@@ -49,7 +54,7 @@ def run_case(name):
     cam = m.load_camera(scene_name)
     f32 = lambda v: [float(np.float32(x)) for x in v]  # noqa: E731
     payload = {
-        "width": w, "height": h, "sample_count": spp, "max_path_length": bounces, "timestamps": ts,
+        "width": w, "height": h, "sample_count": spp, "max_path_length": bounces, "timestamps": ts, "progressive": "_prog_" in name,
         "cam_src": f32(cam["cam_src"]), "cam_dir": f32(cam["cam_dir"]), "cam_up": f32(cam["cam_up"]),
         "cam_right": f32(cam["cam_right"]), "cam_left_bottom": f32(cam["cam_left_bottom"]),
         "vertexShader": open(os.path.join(REF, "vertexShader.glsl")).read(),

@@ -97,14 +97,19 @@
     gl.uniform1i(U('quadX'), 0);
     gl.uniform1i(U('quadY'), 0);
 
-    var prevTex = rgba8Target(gl, p.width, p.height, 0);
-    var curTex = rgba8Target(gl, p.width, p.height, 1);
-    var fb = gl.createFramebuffer();
-    gl.bindFramebuffer(gl.FRAMEBUFFER, fb);
-    gl.framebufferTexture2D(gl.FRAMEBUFFER, gl.COLOR_ATTACHMENT0, gl.TEXTURE_2D, curTex, 0);
-    if (gl.checkFramebufferStatus(gl.FRAMEBUFFER) !== gl.FRAMEBUFFER_COMPLETE) throw new Error('fbo incomplete');
-    gl.activeTexture(gl.TEXTURE0); gl.bindTexture(gl.TEXTURE_2D, prevTex);
-    gl.uniform1i(U('previousFrameTexture'), 0);
+    // two RGBA8 targets with a framebuffer each, used in turn like modules/bufferManager.js:33-43 + main.js:312-324:
+    // frame n renders into target n % 2 and samples target (n + 1) % 2 as previousFrameTexture
+    var tex = [rgba8Target(gl, p.width, p.height, 0), rgba8Target(gl, p.width, p.height, 1)];
+    var fbs = [];
+    for (var k = 0; k < 2; k++) {
+      var fbk = gl.createFramebuffer();
+      gl.bindFramebuffer(gl.FRAMEBUFFER, fbk);
+      gl.framebufferTexture2D(gl.FRAMEBUFFER, gl.COLOR_ATTACHMENT0, gl.TEXTURE_2D, tex[k], 0);
+      if (gl.checkFramebufferStatus(gl.FRAMEBUFFER) !== gl.FRAMEBUFFER_COMPLETE) throw new Error('fbo incomplete');
+      gl.clearColor(0, 0, 0, 1);
+      gl.clear(gl.COLOR_BUFFER_BIT);
+      fbs.push(fbk);
+    }
 
     var vao = gl.createVertexArray();
     gl.bindVertexArray(vao);
@@ -117,9 +122,14 @@
 
     var frames = [], times = [];
     for (var f = 0; f < p.timestamps.length; f++) {
-      // frameNumber = 0 for every frame: blend factor 1 => the un-blended per-frame image (SURVEY.md 8c-1 "Limits")
+      // default: frameNumber = 0 for every frame: blend factor 1 => the un-blended per-frame image (SURVEY.md 8c-1
+      // "Limits"); p.progressive: frameNumber = f, the reference's running blend through the 8-bit targets
+      var n = p.progressive ? f : 0;
       gl.uniform1i(U('timestamp'), p.timestamps[f]);
-      gl.uniform1i(U('frameNumber'), 0);
+      gl.uniform1i(U('frameNumber'), n);
+      gl.activeTexture(gl.TEXTURE0); gl.bindTexture(gl.TEXTURE_2D, tex[(n + 1) % 2]);
+      gl.uniform1i(U('previousFrameTexture'), 0);
+      gl.bindFramebuffer(gl.FRAMEBUFFER, fbs[n % 2]);
       gl.viewport(0, 0, p.width, p.height);
       gl.clearColor(0, 0, 0, 1);
       gl.clear(gl.COLOR_BUFFER_BIT);

@@ -22,7 +22,7 @@ _i = C.POINTER(C.c_int32)
 # every symbol include/ptx.h declares (tests check the library exports all of them)
 SYMBOLS = ["ptx_device_count", "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_upload_scene", "ptx_set_params",
            "ptx_set_option", "ptx_render_frames", "ptx_synchronize", "ptx_reset_accum", "ptx_frames_done",
-           "ptx_read_linear_f32", "ptx_read_sum_f32", "ptx_read_rgba8", "ptx_trace_closest", "ptx_primary_hits",
+           "ptx_read_linear_f32", "ptx_read_sum_f32", "ptx_read_rgba8", "ptx_read_compat_rgba8", "ptx_write_sum_f32", "ptx_trace_closest", "ptx_primary_hits",
            "ptx_primary_dirs", "ptx_get_counters", "ptx_reset_counters", "ptx_accum_export_device",
            "ptx_accum_import_device"]
 
@@ -93,6 +93,8 @@ def load_library():
     L.ptx_read_linear_f32.argtypes = [C.c_void_p, _f]
     L.ptx_read_sum_f32.argtypes = [C.c_void_p, _f]
     L.ptx_read_rgba8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    L.ptx_read_compat_rgba8.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_int, C.c_int]
+    L.ptx_write_sum_f32.argtypes = [C.c_void_p, _f, C.c_uint32]
     L.ptx_trace_closest.argtypes = [C.c_void_p, _f, _f, C.c_uint32, _f, _i]
     L.ptx_primary_hits.argtypes = [C.c_void_p, _i, _f]
     L.ptx_primary_dirs.argtypes = [C.c_void_p, _f]
@@ -196,6 +198,19 @@ class Context:
         out = self._img(4, np.uint8)
         self._check(self._lib.ptx_read_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), int(apply_gamma), int(flip_y)))
         return out
+
+    def read_compat_rgba8(self, apply_gamma=False, flip_y=False):
+        """The reference's RGBA8 ping-pong target (option compat_rgba8 = 1)."""
+        out = self._img(4, np.uint8)
+        self._check(self._lib.ptx_read_compat_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), int(apply_gamma), int(flip_y)))
+        return out
+
+    def write_sum(self, rgb, frames_done):
+        """Checkpoint restore: accumulation := rgb (H, W, 3 float32 as read_sum returned it), frames_done frames in it."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        if rgb.size != self.params.height * self.params.width * 3:
+            raise ValueError("rgb must hold height * width * 3 floats")
+        self._check(self._lib.ptx_write_sum_f32(self._h, _fp(rgb), int(frames_done)))
 
     # ---- parity / roofline hooks
     def trace_closest(self, o, d):

@@ -100,6 +100,47 @@ __global__ __launch_bounds__(256) void k_pack_rgba8(const float4* __restrict__ a
     out[(size_t)oy * W + x] = make_uchar4(q[0], q[1], q[2], 255);
 }
 
+// Reference-compatible progressive blend (option "compat_rgba8"): glsl:532-552 through the RGBA8 ping-pong render targets
+// of modules/bufferManager.js:18 -- out = unorm8(mix(prev, cur, 1 / (frameNumber + 1))), where prev is read back from
+// the 8-bit target with the shader's aspect-shifted texture coordinate (glsl:501-512; NEAREST, REPEAT wrap).
+__global__ __launch_bounds__(256) void k_blend_rgba8(const uchar4* __restrict__ prev, const float4* __restrict__ cur, uchar4* __restrict__ out,
+                                                     uint32_t W, uint32_t H, float aspect, float bf) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= W * H) return;
+    const uint32_t x = p % W, y = p / W;
+    float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
+    if (aspect > 1.0f) { u = u * aspect; u = u - 0.125f; }
+    else if (aspect < 1.0f) { v = v / aspect; v = v - 0.125f; }
+    const float fu = u - floorf(u), fv = v - floorf(v);
+    int sx = (int)floorf(fu * (float)W), sy = (int)floorf(fv * (float)H);
+    if (sx >= (int)W) sx = (int)W - 1;
+    if (sy >= (int)H) sy = (int)H - 1;
+    const uchar4 q = prev[(size_t)sy * W + sx];
+    const float4 c = cur[p];
+    const float pr[3] = {clamp01((float)q.x / 255.0f), clamp01((float)q.y / 255.0f), clamp01((float)q.z / 255.0f)};
+    const float cu[3] = {c.x, c.y, c.z};
+    unsigned char o[3];
+    for (int k = 0; k < 3; k++) {
+        const float b = pr[k] * (1.0f - bf) + cu[k] * bf;      // mix(x, y, a) = x * (1 - a) + y * a
+        o[k] = (unsigned char)floorf(clamp01(b) * 255.0f + 0.5f);
+    }
+    out[p] = make_uchar4(o[0], o[1], o[2], 255);
+}
+
+// display pass over the 8-bit target (shaders/fragmentShaderOutput.glsl:35) + optional flip (main.js:464-473)
+__global__ __launch_bounds__(256) void k_display_rgba8(const uchar4* __restrict__ in, uint32_t W, uint32_t H, int apply_gamma, int flip_y,
+                                                       uchar4* __restrict__ out) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= W * H) return;
+    const uint32_t x = p % W, y = p / W;
+    const uchar4 q = in[p];
+    unsigned char o[3] = {q.x, q.y, q.z};
+    if (apply_gamma)
+        for (int k = 0; k < 3; k++) o[k] = (unsigned char)floorf(clamp01(powf((float)o[k] / 255.0f, 1.0f / 2.2f)) * 255.0f + 0.5f);
+    const uint32_t oy = flip_y ? (H - 1 - y) : y;
+    out[(size_t)oy * W + x] = make_uchar4(o[0], o[1], o[2], 255);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 
 struct ptx_ctx {
@@ -121,6 +162,8 @@ struct ptx_ctx {
     float* d_prim_t = nullptr;
     int* d_prim_tri = nullptr;
     float4* d_accum = nullptr;
+    uchar4* d_compat[2] = {nullptr, nullptr};   // option "compat_rgba8": the reference's two RGBA8 render targets
+    int compat_cur = 0;                         // which of the two holds the newest blend
     uint32_t frames_done = 0;
 
     // batch frame buffers
@@ -130,7 +173,7 @@ struct ptx_ctx {
     size_t ts_cap = 0;
 
     // options
-    int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128;
+    int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128, opt_compat = 0;
 
     // counters + timing
     unsigned long long* d_counters = nullptr;
@@ -219,6 +262,7 @@ static void free_params_buffers(ptx_ctx* ctx) {
     if (ctx->d_prim_t) (void)hipFree(ctx->d_prim_t);
     if (ctx->d_prim_tri) (void)hipFree(ctx->d_prim_tri);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+    for (int k = 0; k < 2; k++) { if (ctx->d_compat[k]) (void)hipFree(ctx->d_compat[k]); ctx->d_compat[k] = nullptr; }
     if (ctx->d_fb) (void)hipFree(ctx->d_fb);
     ctx->d_prim_t = nullptr; ctx->d_prim_tri = nullptr; ctx->d_accum = nullptr; ctx->d_fb = nullptr;
     ctx->fb_frames = 0;
@@ -510,6 +554,8 @@ extern "C" int ptx_reset_accum(ptx_ctx* ctx) {
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_reset_accum: ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), ctx->stream));
+    for (int k = 0; k < 2; k++)
+        if (ctx->d_compat[k]) HIP_TRY(ctx, hipMemsetAsync(ctx->d_compat[k], 0, (size_t)ctx->P.W * ctx->P.H * sizeof(uchar4), ctx->stream));
     ctx->frames_done = 0;
     return PTX_OK;
 }
@@ -553,6 +599,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;
+    else if (k == "compat_rgba8" && (value == 0 || value == 1)) ctx->opt_compat = (int)value;
     else if (k == "frame_batch" && value >= 0 && value <= 4096) ctx->opt_frame_batch = (int)value;
     else if (k == "tasks_per_wave" && value >= 64 && value <= (1 << 20)) ctx->opt_tasks_per_wave = (int)value;
     else return fail(ctx, PTX_ERR_INVALID, "ptx_set_option: unknown key or bad value: " + k);
@@ -618,7 +665,6 @@ static void launch_render_pool(ptx_ctx* ctx, uint32_t nf) {
 extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
     if (!ctx) return PTX_ERR_INVALID;
     if (!timestamps && n_frames) return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames: timestamps is NULL");
-    (void)first_frame_number;
     if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_render_frames: scene and params must be set first");
     if (n_frames == 0) return PTX_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -695,6 +741,20 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         ctx->kernel_launches++;
         hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->d_fb, (uint32_t)npix, nf);
         HIP_TRY(ctx, hipGetLastError());
+        if (ctx->opt_compat) {   // the reference's own progressive blend, one frame after the other through the 8-bit targets
+            for (int k = 0; k < 2; k++)
+                if (!ctx->d_compat[k]) {
+                    HIP_TRY(ctx, hipMalloc(&ctx->d_compat[k], npix * sizeof(uchar4)));
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->d_compat[k], 0, npix * sizeof(uchar4), ctx->stream));
+                }
+            for (uint32_t f = 0; f < nf; f++) {
+                const float bf = 1.0f / (float)(first_frame_number + f0 + f + 1u);        // glsl:537: 1.0 / float(frameNumber + 1)
+                hipLaunchKernelGGL(k_blend_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur],
+                                   ctx->d_fb + (size_t)f * npix, ctx->d_compat[ctx->compat_cur ^ 1], ctx->P.W, ctx->P.H, ctx->P.aspect, bf);
+                ctx->compat_cur ^= 1;
+            }
+            HIP_TRY(ctx, hipGetLastError());
+        }
         ctx->frames_done += nf;
     }
     return PTX_OK;
@@ -753,6 +813,39 @@ extern "C" int ptx_read_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int f
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_read_rgba8: ") + hipGetErrorString(e));
     drain_events(ctx);
+    return PTX_OK;
+}
+
+extern "C" int ptx_read_compat_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int flip_y) {
+    if (!ctx || !out) return PTX_ERR_INVALID;
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
+    if (!ctx->d_compat[0]) return fail(ctx, PTX_ERR_STATE, "ptx_read_compat_rgba8: no frame was rendered with option compat_rgba8 = 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    uchar4* d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_out, npix * sizeof(uchar4)));
+    hipLaunchKernelGGL(k_display_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur], ctx->P.W, ctx->P.H,
+                       apply_gamma, flip_y, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, npix * sizeof(uchar4), hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_read_compat_rgba8: ") + hipGetErrorString(e));
+    drain_events(ctx);
+    return PTX_OK;
+}
+
+// Checkpoint restore: the accumulation becomes `rgb` (W*H*3, as ptx_read_sum_f32 wrote it) with frames_done frames in it.
+extern "C" int ptx_write_sum_f32(ptx_ctx* ctx, const float* rgb, uint32_t frames_done) {
+    if (!ctx || !rgb) return PTX_ERR_INVALID;
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_write_sum_f32: ptx_set_params first");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    std::vector<float4> h(npix);
+    for (size_t i = 0; i < npix; i++) h[i] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 0.f);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_accum, h.data(), npix * sizeof(float4), hipMemcpyHostToDevice));
+    ctx->frames_done = frames_done;
     return PTX_OK;
 }
 

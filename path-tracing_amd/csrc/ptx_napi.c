@@ -273,7 +273,7 @@ static napi_value read_f32(napi_env env, napi_callback_info info, int (*fn)(ptx_
 static napi_value ReadLinear(napi_env env, napi_callback_info info) { return read_f32(env, info, ptx_read_linear_f32); }
 static napi_value ReadSum(napi_env env, napi_callback_info info) { return read_f32(env, info, ptx_read_sum_f32); }
 
-static napi_value ReadRgba8(napi_env env, napi_callback_info info) {
+static napi_value read_u8(napi_env env, napi_callback_info info, int (*fn)(ptx_ctx *, uint8_t *, int, int), const char *usage) {
     napi_value argv[5];
     uint32_t w = 0, h = 0;
     bool gamma = true, flip = true;
@@ -283,14 +283,39 @@ static napi_value ReadRgba8(napi_env env, napi_callback_info info) {
     if (!ctx) return NULL;
     if (napi_get_value_uint32(env, argv[1], &w) != napi_ok || napi_get_value_uint32(env, argv[2], &h) != napi_ok ||
         napi_get_value_bool(env, argv[3], &gamma) != napi_ok || napi_get_value_bool(env, argv[4], &flip) != napi_ok) {
-        napi_throw_type_error(env, NULL, "ptx_napi: readRgba8(handle, width, height, gamma:boolean, flipY:boolean)");
+        napi_throw_type_error(env, NULL, usage);
         return NULL;
     }
     napi_value ta = make_typed(env, napi_uint8_array, (size_t)w * h * 4, 1, &data);
     if (!ta) return NULL;
-    int rc = ptx_read_rgba8(ctx, (uint8_t *)data, gamma, flip);
+    int rc = fn(ctx, (uint8_t *)data, gamma, flip);
     if (rc) return throw_ptx(env, ctx, rc);
     return ta;
+}
+static napi_value ReadRgba8(napi_env env, napi_callback_info info) {
+    return read_u8(env, info, ptx_read_rgba8, "ptx_napi: readRgba8(handle, width, height, gamma:boolean, flipY:boolean)");
+}
+static napi_value ReadCompatRgba8(napi_env env, napi_callback_info info) {
+    return read_u8(env, info, ptx_read_compat_rgba8, "ptx_napi: readCompatRgba8(handle, width, height, gamma:boolean, flipY:boolean)");
+}
+
+/* writeSum(handle, width, height, Float32Array rgb (W*H*3), framesDone): checkpoint restore */
+static napi_value WriteSum(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    uint32_t w = 0, h = 0, frames = 0;
+    if (!get_args(env, info, 5, argv)) return NULL;
+    ptx_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    if (napi_get_value_uint32(env, argv[1], &w) != napi_ok || napi_get_value_uint32(env, argv[2], &h) != napi_ok ||
+        napi_get_value_uint32(env, argv[4], &frames) != napi_ok) {
+        napi_throw_type_error(env, NULL, "ptx_napi: writeSum(handle, width, height, rgb:Float32Array, framesDone)");
+        return NULL;
+    }
+    const float *rgb = (const float *)get_typed(env, argv[3], napi_float32_array, (size_t)w * h * 3, NULL, "rgb");
+    if (!rgb) return NULL;
+    int rc = ptx_write_sum_f32(ctx, rgb, frames);
+    if (rc) return throw_ptx(env, ctx, rc);
+    return NULL;
 }
 
 static napi_value pair_result(napi_env env, napi_value t, napi_value tri) {
@@ -366,7 +391,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount}, {"create", Create}, {"destroy", Destroy}, {"uploadScene", UploadScene}, {"setParams", SetParams},
         {"setOption", SetOption}, {"renderFrames", RenderFrames}, {"resetAccum", ResetAccum}, {"framesDone", FramesDone},
-        {"readLinear", ReadLinear}, {"readSum", ReadSum}, {"readRgba8", ReadRgba8}, {"traceClosest", TraceClosest},
+        {"readLinear", ReadLinear}, {"readSum", ReadSum}, {"readRgba8", ReadRgba8}, {"readCompatRgba8", ReadCompatRgba8}, {"writeSum", WriteSum}, {"traceClosest", TraceClosest},
         {"primaryHits", PrimaryHits}, {"counters", Counters}, {"resetCounters", ResetCounters}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

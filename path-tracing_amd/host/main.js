@@ -11,7 +11,13 @@
  *
  *   node main.js --scene file.gltf|file.obj|file.ptxs [--camera preset | --camera-json file] [--width 256]
  *        [--height 256] [--frames 5] [--spp 5] [--bounces 5] [--out image.png|.ppm] [--dump-sum file.f32]
- *        [--device 0] [--traversal 0|1] [--save-scene out.ptxs] [--light-material name]
+ *        [--device 0] [--traversal 0..3] [--save-scene out.ptxs] [--light-material name]
+ *        [--checkpoint file.ptxc] [--checkpoint-every 16] [--compat-out image.png]
+ * --checkpoint: progressive rendering like renderAsync (main.js:391-436): frames are rendered in batches of
+ *   --checkpoint-every; after each batch {sum buffer, frames done} is written to the file (atomically, via rename).  If
+ *   the file exists when the program starts, rendering resumes after the frames it holds (same size required); the
+ *   timestamp of frame f is always 1000 + f, so a resumed render equals an uninterrupted one bit for bit.
+ * --compat-out: also keep the reference's own RGBA8 ping-pong blend (glsl:532-552) and save it (no gamma, flipped).
  */
 const fs = require('fs');
 const path = require('path');
@@ -55,10 +61,26 @@ function main() {
   pt.uploadScene(scene);
   pt.setParams(a.width, a.height, camera, a.bounces, a.spp);
   if (a.traversal !== undefined) pt.setOption('traversal', a.traversal);
-  const timestamps = [];
-  for (let f = 0; f < a.frames; f++) timestamps.push(1000 + f);
+  if (a.compatOut) {
+    if (a.checkpoint) throw new Error('--compat-out cannot be combined with --checkpoint (the 8-bit target is not checkpointed)');
+    pt.setOption('compat_rgba8', 1);
+  }
+  let first = 0;
+  if (a.checkpoint && fs.existsSync(a.checkpoint)) {
+    const ck = readCheckpoint(a.checkpoint);
+    if (ck.width !== a.width || ck.height !== a.height) throw new Error('checkpoint is ' + ck.width + 'x' + ck.height + ', not ' + a.width + 'x' + a.height);
+    pt.writeSum(ck.sum, ck.framesDone);
+    first = ck.framesDone;
+    console.log('resumed ' + a.checkpoint + ' at frame ' + first);
+  }
+  const every = a.checkpoint ? Math.max(1, a.checkpointEvery || 16) : Math.max(1, a.frames);
   const t1 = Date.now();
-  pt.renderFrames(timestamps, 0);
+  for (let f0 = first; f0 < a.frames; f0 += every) {
+    const timestamps = [];
+    for (let f = f0; f < Math.min(a.frames, f0 + every); f++) timestamps.push(1000 + f);
+    pt.renderFrames(timestamps, f0);
+    if (a.checkpoint) writeCheckpoint(a.checkpoint, a.width, a.height, pt.framesDone, pt.readSum());
+  }
   const dt = (Date.now() - t1) / 1000;
   const c = pt.counters();
   console.log(`rendered ${a.frames} frames x ${a.spp} spp at ${a.width}x${a.height}, ${a.bounces} bounces in ${dt.toFixed(3)} s: ` +
@@ -69,7 +91,31 @@ function main() {
     (path.extname(a.out) === '.ppm' ? writePPM : writePNG)(a.out, px, a.width, a.height);
     console.log('wrote ' + a.out);
   }
+  if (a.compatOut) {
+    const px = pt.readCompatRgba8(false, true);
+    (path.extname(a.compatOut) === '.ppm' ? writePPM : writePNG)(a.compatOut, px, a.width, a.height);
+    console.log('wrote ' + a.compatOut);
+  }
   pt.destroy();
+}
+
+// checkpoint file: 'PTXC' u32 version(1) u32 width u32 height u32 framesDone, then width*height*3 f32 (the raw sum)
+function writeCheckpoint(file, width, height, framesDone, sum) {
+  const head = Buffer.alloc(20);
+  head.write('PTXC', 0, 'latin1');
+  head.writeUInt32LE(1, 4); head.writeUInt32LE(width, 8); head.writeUInt32LE(height, 12); head.writeUInt32LE(framesDone, 16);
+  fs.writeFileSync(file + '.tmp', Buffer.concat([head, Buffer.from(sum.buffer, sum.byteOffset, sum.byteLength)]));
+  fs.renameSync(file + '.tmp', file);
+}
+
+function readCheckpoint(file) {
+  const b = fs.readFileSync(file);
+  if (b.length < 20 || b.toString('latin1', 0, 4) !== 'PTXC' || b.readUInt32LE(4) !== 1) throw new Error(file + ' is not a PTXC v1 checkpoint');
+  const width = b.readUInt32LE(8), height = b.readUInt32LE(12), framesDone = b.readUInt32LE(16);
+  if (b.length !== 20 + width * height * 12) throw new Error(file + ': truncated checkpoint');
+  const sum = new Float32Array(width * height * 3);
+  Buffer.from(sum.buffer).set(b.subarray(20));
+  return { width, height, framesDone, sum };
 }
 
 try { main(); } catch (e) { console.error(String(e && e.message || e)); process.exit(1); }

@@ -42,6 +42,10 @@ class PathTracer {
   readLinear() { return this.addon.readLinear(this.handle, this.width, this.height); }
   readSum() { return this.addon.readSum(this.handle, this.width, this.height); }
   readRgba8(gamma, flipY) { return this.addon.readRgba8(this.handle, this.width, this.height, gamma !== false, flipY !== false); }
+  /** The reference's RGBA8 ping-pong target (setOption('compat_rgba8', 1) before rendering): what gl.readPixels returns in the browser. */
+  readCompatRgba8(gamma, flipY) { return this.addon.readCompatRgba8(this.handle, this.width, this.height, gamma === true, flipY === true); }
+  /** Checkpoint restore: accumulation := sum (Float32Array W*H*3 from readSum()), holding framesDone frames. */
+  writeSum(sum, framesDone) { this.addon.writeSum(this.handle, this.width, this.height, sum, framesDone); }
   traceClosest(origins, directions) { return this.addon.traceClosest(this.handle, Float32Array.from(origins), Float32Array.from(directions)); }
   primaryHits() { return this.addon.primaryHits(this.handle, this.width, this.height); }
   counters() { return this.addon.counters(this.handle); }

@@ -168,6 +168,24 @@ def test_accumulation_semantics(gpu_ctx, ptx, orc):
     assert (gpu_ctx.read_rgba8(False, False) == orc.blend_rgba8(p, one, None, 0)).all()
 
 
+def test_checkpoint_restore(gpu_ctx, ptx):
+    """ptx_write_sum_f32: a render resumed from {sum, frames_done} equals the uninterrupted one bit for bit."""
+    s, p = setup(gpu_ctx, ptx, "my_cornell_6", 40, 24, spp=3, bounces=4)
+    ts = ptx.scene.timestamps(5)
+    gpu_ctx.render_frames(ts)
+    want = gpu_ctx.read_sum()
+    gpu_ctx.reset_accum(); gpu_ctx.render_frames(ts[:2])
+    ck, n = gpu_ctx.read_sum(), gpu_ctx.frames_done
+    gpu_ctx.reset_accum()
+    assert gpu_ctx.frames_done == 0
+    gpu_ctx.write_sum(ck, n)
+    assert gpu_ctx.frames_done == 2
+    gpu_ctx.render_frames(ts[2:], first_frame_number=2)
+    assert gpu_ctx.frames_done == 5 and (bits(gpu_ctx.read_sum()) == bits(want)).all()
+    with pytest.raises(ValueError):
+        gpu_ctx.write_sum(ck[:3], 1)
+
+
 def test_device_export_import_for_allreduce(gpu_ctx, ptx):
     import torch
     s, p = setup(gpu_ctx, ptx, "my_cornell_6", 32, 16, spp=2, bounces=2)

@@ -29,7 +29,19 @@ def check(case, frames_rgba8, ref):
         same = (mine == want).all(axis=2).mean()
         dmax = np.abs(mine.astype(np.int32) - want.astype(np.int32)).max()
         dmean = abs(mine[..., :3].mean() - want[..., :3].mean())
-        if bounces == 1:
+        if "_prog_" in case:
+            # Running blend through the 8-bit targets: +-1 code value per frame from the sin/cos freedom, carried along.
+            # On wide images the shader reads the previous target at an aspect-shifted coordinate (glsl:501-512) that
+            # falls EXACTLY on a texel boundary in some columns (16:9: every 9th); which texel NEAREST picks there is
+            # implementation-defined (SwiftShader quantises coordinates to 16 bits and lands one texel lower in some
+            # of them), so those columns may differ by more.
+            big = (np.abs(mine.astype(np.int32) - want.astype(np.int32)).max(axis=2) > 1)
+            cols = np.unique(np.nonzero(big)[1])
+            w = mine.shape[1]
+            aspect = np.float32(w / mine.shape[0])
+            on_boundary = [abs(((x + 0.5) / w * aspect - 0.125) * w - round(((x + 0.5) / w * aspect - 0.125) * w)) < 1e-3 for x in cols]
+            assert same >= 0.96 and all(on_boundary) and (aspect > 1 or not big.any()), (case, f, same, cols)
+        elif bounces == 1:
             assert same >= 0.995 and dmax <= 1, (case, f, same, dmax)
         else:
             assert dmean <= 0.01 * max(1.0, want[..., :3].mean()) + 0.3, (case, f, dmean)      # unbiased
@@ -56,7 +68,13 @@ def test_fixtures_present():
 def test_oracle_matches_reference_shader(ptx, orc, case):
     ref, s, p = load(ptx, case)
     assert "SwiftShader" in str(ref["renderer"])
-    frames = [orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], None, 0) for ts in ref["timestamps"]]
+    if "_prog_" in case:      # the reference's running blend: frameNumber = f, previous 8-bit target fed back (glsl:532-552)
+        frames, prev = [], None
+        for f, ts in enumerate(ref["timestamps"]):
+            prev = orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], prev, f)
+            frames.append(prev)
+    else:
+        frames = [orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], None, 0) for ts in ref["timestamps"]]
     check(case, frames, ref)
 
 
@@ -67,8 +85,19 @@ def test_gpu_matches_reference_shader(ptx, gpu_ctx, case):
     gpu_ctx.upload_scene(s)
     gpu_ctx.set_params(p)
     frames = []
-    for ts in ref["timestamps"]:
+    if "_prog_" in case:      # option compat_rgba8: the library keeps the reference's two 8-bit targets itself
+        gpu_ctx.set_option("compat_rgba8", 1)
         gpu_ctx.reset_accum()
-        gpu_ctx.render_frames([int(ts)])
-        frames.append(gpu_ctx.read_rgba8(apply_gamma=False, flip_y=False))   # == the reference's RGBA8 target at frameNumber 0
+        for f, ts in enumerate(ref["timestamps"]):
+            gpu_ctx.render_frames([int(ts)], first_frame_number=f)
+            frames.append(gpu_ctx.read_compat_rgba8())
+        gpu_ctx.reset_accum()                                                  # the same frames in one call (one batch)
+        gpu_ctx.render_frames([int(ts) for ts in ref["timestamps"]])
+        assert (gpu_ctx.read_compat_rgba8() == frames[-1]).all()
+        gpu_ctx.set_option("compat_rgba8", 0)
+    else:
+        for ts in ref["timestamps"]:
+            gpu_ctx.reset_accum()
+            gpu_ctx.render_frames([int(ts)])
+            frames.append(gpu_ctx.read_rgba8(apply_gamma=False, flip_y=False))   # == the reference's RGBA8 target at frameNumber 0
     check(case, frames, ref)
