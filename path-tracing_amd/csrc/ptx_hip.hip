@@ -406,7 +406,7 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n
             it.mn[k] = sc->node_min[3 * (size_t)i + k]; it.mx[k] = sc->node_max[3 * (size_t)i + k];
             it.cen[k] = 0.5f * it.mn[k] + 0.5f * it.mx[k];
         }
-        it.fc = sc->node_first[i] | (sc->node_count[i] << 24);
+        it.fc = sc->node_count[i] == 0 ? -2 : (sc->node_first[i] | (sc->node_count[i] << 24));
         it.w = std::max(1, sc->node_count[i]);
         items.push_back(it);
     }
@@ -474,7 +474,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         const float* mn = sc->node_min + 3 * (size_t)i;
         const float* mx = sc->node_max + 3 * (size_t)i;
         const int32_t f = sc->node_first[i];
-        const int32_t fc = (f == -2) ? -2 : (f | (sc->node_count[i] << 24));
+        const int32_t fc = (f == -2 || sc->node_count[i] == 0) ? -2 : (f | (sc->node_count[i] << 24));   // an empty leaf walks like an inner node
         nodes[2 * (size_t)i] = make_float4(mn[0], mn[1], mn[2], bits(sc->node_miss[i]));
         nodes[2 * (size_t)i + 1] = make_float4(mx[0], mx[1], mx[2], bits(fc));
     }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     if (COUNT) cnt_nodes++;
                     bool hit = slab_node(ro, inv, a, b, tn);
                     if (PRUNE) hit = hit && !(tn > limit);
-                    push = hit && fc != -2 && (fc >> 24) != 0;       // internal nodes and empty leaves queue nothing
+                    push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
                     item = ((uint32_t)fc & 0x00FFFFFFu) | (lane << 24);
                     i = hit ? i + 1u : (uint32_t)miss;
                 }
