@@ -116,7 +116,9 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 exactly as glsl:532-552 + modules/bufferManager.js:18 do (8-bit rounding per frame, the aspect-shifted
  *                 read of the previous target included); read it with ptx_read_compat_rgba8.  0 = off (default)
  *   "frame_batch": max frames rendered concurrently (0 = auto)
- *   "tasks_per_wave": (pixel, frame) tasks one wave of pipeline 1 / 2 works through (default 128)
+ *   "tasks_per_wave": (pixel, frame) tasks one wave of pipeline 1 works through (default 128)
+ *   "pool_chunk": pipeline 2 runs one chip residency of persistent waves; each draws this many tasks at a time from a
+ *                 global counter until the launch is exhausted (default 64 = one 8x8 tile)
  */
 int ptx_set_option(ptx_ctx *ctx, const char *key, int64_t value);
 

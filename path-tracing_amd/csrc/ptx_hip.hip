@@ -173,10 +173,12 @@ struct ptx_ctx {
     size_t ts_cap = 0;
 
     // options
-    int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128, opt_compat = 0;
+    int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128, opt_compat = 0, opt_pool_chunk = 64;
 
     // counters + timing
     unsigned long long* d_counters = nullptr;
+    uint32_t* d_task_counter = nullptr;       // pipeline 2: next undrawn (pixel, frame) task of the running launch
+    int pool_blocks = 0;                       // pipeline 2: waves that are resident at once on this device
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<hipEvent_t> free_events;
     double kernel_ms = 0.0;
@@ -243,7 +245,8 @@ extern "C" ptx_ctx* ptx_create(const int* device_ids, int n_devices) {
     ctx->device = device_ids[0];
     if ((e = hipSetDevice(ctx->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&ctx->d_counters, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc(&ctx->d_task_counter, sizeof(uint32_t))) != hipSuccess) {
         g_create_error = std::string("ptx_create: ") + hipGetErrorString(e);
         delete ctx;
         return nullptr;
@@ -277,6 +280,7 @@ extern "C" void ptx_destroy(ptx_ctx* ctx) {
     free_params_buffers(ctx);
     if (ctx->d_ts) (void)hipFree(ctx->d_ts);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_task_counter) (void)hipFree(ctx->d_task_counter);
     for (auto& pr : ctx->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto ev : ctx->free_events) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -599,6 +603,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;
+    else if (k == "pool_chunk" && value >= 1 && value <= 65536) ctx->opt_pool_chunk = (int)value;
     else if (k == "compat_rgba8" && (value == 0 || value == 1)) ctx->opt_compat = (int)value;
     else if (k == "frame_batch" && value >= 0 && value <= 4096) ctx->opt_frame_batch = (int)value;
     else if (k == "tasks_per_wave" && value >= 64 && value <= (1 << 20)) ctx->opt_tasks_per_wave = (int)value;
@@ -655,11 +660,16 @@ static void launch_render_wave(ptx_ctx* ctx, uint32_t nf) {
 template <bool PRUNE, bool MEMO, bool COUNT>
 static void launch_render_pool(ptx_ctx* ctx, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
-    const uint64_t total = (uint64_t)tiles * 64u * nf;
-    const uint32_t per_wave = (uint32_t)ctx->opt_tasks_per_wave;
-    const uint32_t blocks = (uint32_t)((total + per_wave - 1) / per_wave);
+    const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32 - 2^28: ptx_render_frames caps the batch
+    const uint32_t chunk = (uint32_t)ctx->opt_pool_chunk;
+    int per_cu = 0, cus = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64, 0);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint64_t resident = (uint64_t)std::max(1, per_cu) * (uint64_t)std::max(1, cus);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident, (total + chunk - 1) / chunk);
+    (void)hipMemsetAsync(ctx->d_task_counter, 0, sizeof(uint32_t), ctx->stream);
     hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
-                       ctx->d_prim_tri, ctx->d_fb, nf, per_wave, ctx->d_counters);
+                       ctx->d_prim_tri, ctx->d_fb, nf, chunk, ctx->d_task_counter, ctx->d_counters);
 }
 
 extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
@@ -678,7 +688,7 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
     if (ctx->opt_pipeline != 0) batch = std::min<size_t>(batch, 64);   // pipelines 1 and 2 keep the frame-in-batch in 6 bits
     {   // pipeline 1 indexes (pixel, frame) tasks with 32 bits
         const uint64_t padded = (uint64_t)((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8) * 64u;
-        batch = std::max<size_t>(1, std::min<size_t>(batch, (size_t)(0xF0000000ull / padded)));
+        batch = std::max<size_t>(1, std::min<size_t>(batch, (size_t)(0xE0000000ull / padded)));
     }
     if (ctx->fb_frames < batch) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

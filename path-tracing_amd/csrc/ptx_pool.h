@@ -21,7 +21,7 @@
 #define PTX_POOL_WALK_STEPS 16   // node steps per WALK phase (ends early when the queue could overflow)
 #endif
 #ifndef PTX_POOL_SHADE_W
-#define PTX_POOL_SHADE_W 4       // a lane waiting for SHADE weighs this many QUARTERS of a walking lane / queued leaf in the vote
+#define PTX_POOL_SHADE_W 3       // a lane waiting for SHADE weighs this many QUARTERS of a walking lane / queued leaf in the vote
 #endif
 
 #ifndef PTX_POOL_MIN_WAVES
@@ -35,8 +35,8 @@ namespace ptx {
 template <bool PRUNE, bool MEMO, bool COUNT>
 __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
                                                     const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
-                                                    float4* __restrict__ fb, uint32_t n_frames, uint32_t tasks_per_wave,
-                                                    unsigned long long* counters) {
+                                                    float4* __restrict__ fb, uint32_t n_frames, uint32_t chunk,
+                                                    uint32_t* __restrict__ task_counter, unsigned long long* counters) {
     __shared__ float lds[PW_C_SAMPLES * 64];         // path state only: the work counters are wave totals in wcnt[]
     __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
     __shared__ uint2 queue[PTX_POOL_QCAP];
@@ -46,8 +46,11 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     const uint32_t tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
     const uint32_t tasks_per_frame = tiles_x * tiles_y * 64u;          // padded to whole 8x8 tiles
     const uint32_t total = tasks_per_frame * n_frames;                 // host guarantees < 2^32
-    uint32_t next = blockIdx.x * tasks_per_wave;                       // wave-uniform cursor into the task list
-    const uint32_t last = (total - next > tasks_per_wave) ? next + tasks_per_wave : total;
+    // Persistent waves: the grid is one residency of the chip, and every wave draws `chunk` tasks at a time from a global
+    // counter until the launch's task list is exhausted.  No wave runs dry while work is left, so lanes only idle during
+    // the last chunk of the whole launch.
+    uint32_t next = 0, last = 0;                                       // wave-uniform cursor into the current chunk
+    bool exhausted = false;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     keys[lane] = PTX_POOL_KEY_NONE;
@@ -164,13 +167,20 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             for (;;) {
                 const unsigned long long m = __ballot(want_task);
                 if (m == 0) break;
+                if (next == last && !exhausted) {                          // wave-uniform: draw the next chunk
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(task_counter, chunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (base >= total) exhausted = true;
+                    else { next = base; last = (total - base > chunk) ? base + chunk : total; }
+                }
                 const uint32_t mine = next + (uint32_t)__popcll(m & lt_mask);
                 const uint32_t avail = last - next;
                 next += min((uint32_t)__popcll(m), avail);
                 bool black = false;
                 if (want_task) {
                     if (mine >= last) {
-                        flags = 0; want_task = false;
+                        if (exhausted) { flags = 0; want_task = false; }   // else: draws from the next chunk in the next round
                     } else {
                         const uint32_t frame = mine / tasks_per_frame;
                         const uint32_t r = mine - frame * tasks_per_frame;
