@@ -24,6 +24,10 @@
 #define PTX_POOL_SHADE_W 3       // a lane waiting for SHADE weighs this many QUARTERS of a walking lane / queued leaf in the vote
 #endif
 
+#ifndef PTX_POOL_WALK_KEEP
+#define PTX_POOL_WALK_KEEP 0     // leave a WALK phase early once no more than KEEP/8 of the lanes it started with still walk
+#endif
+
 #ifndef PTX_POOL_MIN_WAVES
 #define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
 #endif
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 }
                 tail += (uint32_t)__popcll(m);
                 if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
-                if (__ballot(trav && i < N) == 0ull) break;
+                if (__popcll(__ballot(trav && i < N)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
             }
         } else if (phase == 1) {
             const uint32_t n = min(len, 64u);

@@ -140,6 +140,56 @@ def test_edge_cases(gpu_ctx, ptx, orc):
     assert gpu_ctx.frames_done == 1
 
 
+def collapse_tree(ptx, s, max_depth):
+    """The same scene with every subtree below `max_depth` folded into one big leaf (leaf ranges are contiguous because the
+    inorder list is the pre-order concatenation of the leaves): exercises leaf sizes the reference builder never makes."""
+    n = s.N
+    depth = np.zeros(n, dtype=np.int64)
+    end = np.where(s.node_miss < 0, n, s.node_miss)                 # pre-order index after the node's subtree
+    for i in range(n):
+        if s.node_first[i] == -2:                                   # children: i + 1 and miss[i + 1]
+            depth[i + 1] = depth[i] + 1
+            depth[s.node_miss[i + 1]] = depth[i] + 1
+    keep = [i for i in range(n) if depth[i] <= max_depth]
+    new_index = {old: k for k, old in enumerate(keep)}
+    first, count, miss = [], [], []
+    for i in keep:
+        leaves = [j for j in range(i, end[i]) if s.node_first[j] != -2]
+        if s.node_first[i] == -2 and depth[i] < max_depth:
+            first.append(-2); count.append(0)
+        else:
+            first.append(int(s.node_first[leaves[0]])); count.append(int(sum(s.node_count[j] for j in leaves)))
+        miss.append(-1 if s.node_miss[i] < 0 else new_index[int(s.node_miss[i])])
+    k = np.asarray(keep)
+    return ptx.scene.Scene(T=s.T, N=len(keep), L=s.L, coords=s.coords, normals=s.normals, colors=s.colors, emissions=s.emissions,
+                           light_tri=s.light_tri, node_min=np.ascontiguousarray(s.node_min.reshape(-1, 3)[k].reshape(-1)),
+                           node_max=np.ascontiguousarray(s.node_max.reshape(-1, 3)[k].reshape(-1)), node_miss=np.asarray(miss, dtype=np.int32),
+                           node_first=np.asarray(first, dtype=np.int32), node_count=np.asarray(count, dtype=np.int32), inorder_tri=s.inorder_tri)
+
+
+@pytest.mark.parametrize("name,max_depth", [("my_cornell_6", 0), ("my_cornell_6", 2), ("my_cornell_6", 3), ("bedroom2_v5", 5), ("cornell", 1)])
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_big_and_uneven_leaves(gpu_ctx, ptx, orc, name, max_depth, pipeline):
+    """Leaves of 1..127 triangles (odd and even counts, a single-leaf tree): the pair records and the multi-round TRI loop."""
+    s = collapse_tree(ptx, ptx.load_scene(name), max_depth)
+    s.validate()
+    assert s.node_count.max() > 5 and s.node_count.max() <= 127
+    p = ptx.config_params(name, 40, 28, 3, 4)
+    gpu_ctx.upload_scene(s); gpu_ctx.set_params(p)
+    ts = ptx.scene.timestamps(2)
+    want, oc = orc.render_frames(s, p, ts)
+    assert want.max() > 0
+    for traversal in (0, 1, 2, 3):
+        for k, v in dict(traversal=traversal, memo=1, count=1, pipeline=pipeline, frame_batch=0).items():
+            gpu_ctx.set_option(k, v)
+        gpu_ctx.reset_accum(); gpu_ctx.reset_counters()
+        gpu_ctx.render_frames(ts)
+        assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), traversal
+        c = gpu_ctx.counters()
+        assert c["rays"] == oc["rays"] and c["ray_hits"] == oc["ray_hits"]
+    gpu_ctx.set_option("count", 0)
+
+
 def test_accumulation_semantics(gpu_ctx, ptx, orc):
     s, p = setup(gpu_ctx, ptx, "my_cornell_6", 40, 24, spp=2, bounces=3)
     ts = ptx.scene.timestamps(7)
