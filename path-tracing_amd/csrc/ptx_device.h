@@ -110,6 +110,21 @@ __device__ __forceinline__ bool slab_node(V3 o, V3 inv, float4 a, float4 b, floa
     return (tn <= tf) && (tf > 0.0f);
 }
 
+// The slab test on a record whose planes are stored entry-first for the ray's direction octant (leaf-SAH layouts):
+// with 1/d finite and sign(1/d[k]) as the layout assumes, fl(near - o) * inv <= fl(far - o) * inv holds per axis (rounding is
+// monotone), so min(t1, t2) IS the entry value and max(t1, t2) the exit value: the six selections of glsl:182-186 disappear.
+// Only for rays whose 1/d has no infinite component (0 * inf = NaN would make the selection matter); others use slab_node.
+__device__ __forceinline__ bool slab_node_ordered(V3 o, V3 inv, float4 a, float4 b, float& tNear) {
+    const f2 oxy = {o.x, o.y}, ixy = {inv.x, inv.y}, ozz = {o.z, o.z}, izz = {inv.z, inv.z};
+    const f2 en = (f2{a.x, a.y} - oxy) * ixy;     // entry x, y
+    const f2 ex = (f2{a.z, a.w} - oxy) * ixy;     // exit x, y
+    const f2 zz = (f2{b.x, b.y} - ozz) * izz;     // entry z, exit z
+    const float tn = fmaxf(fmaxf(en.x, en.y), zz.x);
+    const float tf = fminf(fminf(ex.x, ex.y), zz.y);
+    tNear = tn;
+    return (tn <= tf) && (tf > 0.0f);
+}
+
 // 1.0f / a for the Moeller-Trumbore determinant.  v_rcp_f32 followed by one Newton step in FMAs gives the correctly rounded
 // quotient for EVERY binary32 a with 1e-4 <= |a| < 2^100 (checked exhaustively on gfx950: tools/dbg/rcpcheck.hip), in 3
 // instructions instead of the 11 of the IEEE division expansion.  |a| < 1e-4 is rejected by the caller whatever f is

@@ -430,6 +430,15 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n
         for (int32_t i = 0; i < N2; i++) {
             int32_t m; std::memcpy(&m, &out[2 * (base + i)].w, 4);
             if (m >= N2) out[2 * (base + i)].w = bits(-1);
+            // Near plane first: in the layout of an octant with d[k] < 0 the two bounds of axis k trade places, so a ray of
+            // that octant finds its entry plane in the "min" position and its exit plane in the "max" position.  The slab
+            // test's min(t1, t2) / max(t1, t2) are symmetric in the two planes, so every kernel reads these records unchanged;
+            // pipeline 2 uses the order to drop the six min/max (slab_node_ordered).
+            float4& lo = out[2 * (base + i)];
+            float4& hi = out[2 * (base + i) + 1];
+            if (oct & 1) std::swap(lo.x, hi.x);
+            if (oct & 2) std::swap(lo.y, hi.y);
+            if (oct & 4) std::swap(lo.z, hi.z);
         }
     }
     *n2 = N2;

@@ -13,6 +13,7 @@
 // A ray is finished when its walk has ended and the queue head has passed its newest item (items are consumed in order).
 #pragma once
 #include "ptx_wave.h"
+#include <type_traits>
 
 #ifndef PTX_POOL_QCAP
 #define PTX_POOL_QCAP 128        // queue entries per wave (power of two, >= 128: one WALK step may add 64)
@@ -94,35 +95,40 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
 
         if (phase == 0) {
             if (PRUNE) limit = __uint_as_float((uint32_t)(keys[lane] >> 32)) * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+            // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
+            const bool ordered = S.oct_stride != 0u && __ballot(walking && (flags & F_INF)) == 0ull;
+            auto walk = [&](auto ORDERED) {
 #pragma nounroll
-            for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
-                if (tail - head > (uint32_t)(PTX_POOL_QCAP - 64)) break;
-                const bool w = trav && i < N;
-                bool push = false;
-                uint32_t item = 0;
-                float tn = 0.f;
-                if (w) {
-                    const float4 a = ld16(S.nodes, nbase + (i << 5));
-                    const float4 b = ld16(nodes_hi, nbase + (i << 5));
-                    int miss = __float_as_int(b.z), fc = __float_as_int(b.w);
-                    asm volatile("" : "+v"(miss), "+v"(fc));     // keep the links in the record's two loads (no third, dependent one)
-                    if (COUNT) cnt_nodes++;
-                    bool hit = slab_node(ro, inv, a, b, tn);
-                    if (PRUNE) hit = hit && !(tn > limit);
-                    push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
-                    item = ((uint32_t)fc & 0x00FFFFFFu) | (lane << 24);
-                    i = hit ? i + 1u : (uint32_t)miss;
+                for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
+                    if (tail - head > (uint32_t)(PTX_POOL_QCAP - 64)) break;
+                    const bool w = trav && i < N;
+                    bool push = false;
+                    uint32_t item = 0;
+                    float tn = 0.f;
+                    if (w) {
+                        const float4 a = ld16(S.nodes, nbase + (i << 5));
+                        const float4 b = ld16(nodes_hi, nbase + (i << 5));
+                        int miss = __float_as_int(b.z), fc = __float_as_int(b.w);
+                        asm volatile("" : "+v"(miss), "+v"(fc));     // keep the links in the record's two loads (no third, dependent one)
+                        if (COUNT) cnt_nodes++;
+                        bool hit = decltype(ORDERED)::value ? slab_node_ordered(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
+                        if (PRUNE) hit = hit && !(tn > limit);
+                        push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
+                        item = ((uint32_t)fc & 0x00FFFFFFu) | (lane << 24);
+                        i = hit ? i + 1u : (uint32_t)miss;
+                    }
+                    const unsigned long long m = __ballot(push);
+                    if (push) {
+                        const uint32_t pos = tail + (uint32_t)__popcll(m & lt_mask);
+                        queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(item, __float_as_uint(tn));
+                        lastpos = pos + 1u;
+                    }
+                    tail += (uint32_t)__popcll(m);
+                    if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
+                    if (__popcll(__ballot(trav && i < N)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
                 }
-                const unsigned long long m = __ballot(push);
-                if (push) {
-                    const uint32_t pos = tail + (uint32_t)__popcll(m & lt_mask);
-                    queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(item, __float_as_uint(tn));
-                    lastpos = pos + 1u;
-                }
-                tail += (uint32_t)__popcll(m);
-                if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
-                if (__popcll(__ballot(trav && i < N)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
-            }
+            };
+            if (ordered) walk(std::true_type{}); else walk(std::false_type{});
         } else if (phase == 1) {
             const uint32_t n = min(len, 64u);
             const bool has = lane < n;
@@ -259,6 +265,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 i = 0;
                 lastpos = head;
                 flags |= F_TRAV;
+                // |x| < inf is false for inf and NaN: such rays keep the selecting slab test
+                flags = (fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff()) ? (flags & ~F_INF) : (flags | F_INF);
             }
             w_traced += (uint32_t)__popcll(__ballot(start_trav));
         }
