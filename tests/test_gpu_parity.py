@@ -190,6 +190,29 @@ def test_big_and_uneven_leaves(gpu_ctx, ptx, orc, name, max_depth, pipeline):
     gpu_ctx.set_option("count", 0)
 
 
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_axis_aligned_rays(gpu_ctx, ptx, orc, pipeline):
+    """Rays with exactly zero direction components (1/d = inf, 0 * inf = NaN slabs): the middle row and column of an
+    axis-aligned camera with an odd image size, traced in the kernel itself (memo = 0).  Pipeline 2 must send them through
+    the selecting slab test, not the entry-first shortcut."""
+    s = ptx.load_scene("my_cornell_6")
+    p = ptx.scene.Params(width=5, height=5, cam_src=[12.4, 0, 0], cam_up=[0, 1, 0], cam_right=[0, 0, -1], cam_left_bottom=[11.4, -0.5, 0.5],
+                         max_path_length=4, sample_count=6)
+    d = orc.primary_dirs(p)
+    assert (d[2, :, 1] == 0).all() and (d[:, 2, 2] == 0).all()
+    gpu_ctx.upload_scene(s); gpu_ctx.set_params(p)
+    ts = ptx.scene.timestamps(3)
+    want, _ = orc.render_frames(s, p, ts)
+    assert want.max() > 0
+    for traversal in (0, 1, 2, 3):
+        for memo in (0, 1):
+            for k, v in dict(traversal=traversal, memo=memo, count=0, pipeline=pipeline, frame_batch=0).items():
+                gpu_ctx.set_option(k, v)
+            gpu_ctx.reset_accum()
+            gpu_ctx.render_frames(ts)
+            assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (traversal, memo)
+
+
 def test_accumulation_semantics(gpu_ctx, ptx, orc):
     s, p = setup(gpu_ctx, ptx, "my_cornell_6", 40, 24, spp=2, bounces=3)
     ts = ptx.scene.timestamps(7)
