@@ -114,13 +114,13 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                         bool hit = decltype(ORDERED)::value ? slab_node_ordered(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
                         if (PRUNE) hit = hit && !(tn > limit);
                         push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
-                        item = ((uint32_t)fc & 0x00FFFFFFu) | (lane << 24);
+                        item = (uint32_t)fc;
                         i = hit ? i + 1u : (uint32_t)miss;
                     }
                     const unsigned long long m = __ballot(push);
                     if (push) {
                         const uint32_t pos = tail + (uint32_t)__popcll(m & lt_mask);
-                        queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(item, __float_as_uint(tn));
+                        queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2((item & 0x00FFFFFFu) | (lane << 24), __float_as_uint(tn));
                         lastpos = pos + 1u;
                     }
                     tail += (uint32_t)__popcll(m);
@@ -136,6 +136,13 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             head += n;
             const uint32_t owner = has ? ((it.x >> 24) & 63u) : lane;
             const uint32_t first = it.x & 0x00FFFFFFu;
+            // the first pair record of the leaf is requested at once, so its latency overlaps the LDS traffic below
+            uint32_t pbyte = first * 80u;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0, r4 = r0;
+            if (has) {
+                r0 = ld16(S.pairs, pbyte); r1 = ld16(S.pairs, pbyte + 16u); r2 = ld16(S.pairs, pbyte + 32u);
+                r3 = ld16(S.pairs, pbyte + 48u); r4 = ld16(S.pairs, pbyte + 64u);
+            }
             // the owner's ray, straight out of the owner's registers (every lane executes the shuffles)
             const V3 o = mk(__shfl(ro.x, (int)owner), __shfl(ro.y, (int)owner), __shfl(ro.z, (int)owner));
             const V3 d = mk(__shfl(rd.x, (int)owner), __shfl(rd.y, (int)owner), __shfl(rd.z, (int)owner));
@@ -146,14 +153,11 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             }
             float bt = 1.0e38f;
             uint32_t bk = 0xFFFFFFFFu;
-            uint32_t k = first;                               // slot of triangle A of the pair; the pair record is pairs[k0 + round]
-            uint32_t pbyte = first * 80u;
+            uint32_t k = first;                               // slot of triangle A of the pair; the pair record is pairs[first + round]
             bool more = go;
             while (__ballot(more) != 0ull) {
                 if (COUNT) { d_tri += more ? 1u : 0u; if (lane == 0) d_tri_s += 64u; }
                 if (more) {
-                    const float4 r0 = ld16(S.pairs, pbyte), r1 = ld16(S.pairs, pbyte + 16u), r2 = ld16(S.pairs, pbyte + 32u),
-                                 r3 = ld16(S.pairs, pbyte + 48u), r4 = ld16(S.pairs, pbyte + 64u);
                     const int rem = __float_as_int(r4.z);      // triangles of the leaf from this pair on (>= 1)
                     bool hA, hB;
                     float tA, tB;
@@ -163,7 +167,11 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     if (hB && tB < bt) { bt = tB; bk = k + 1u; }
                     more = rem > 2;
                     k += 2u;
-                    pbyte += 80u;
+                    if (more) {
+                        pbyte += 80u;
+                        r0 = ld16(S.pairs, pbyte); r1 = ld16(S.pairs, pbyte + 16u); r2 = ld16(S.pairs, pbyte + 32u);
+                        r3 = ld16(S.pairs, pbyte + 48u); r4 = ld16(S.pairs, pbyte + 64u);
+                    }
                 }
             }
             if (bt < 1.0e38f) atomicMin(&keys[owner], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)bk);
