@@ -111,7 +111,8 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *   "count"     : 1 = also count node visits / triangle tests (slower), 0 = off (default)
  *   "pipeline"  : 0 = one lane per (pixel, frame), rays traced one at a time; 1 = wave-scheduled, per-lane leaf queues:
  *                 per-lane walk / triangle / shade work voted per wave, persistent lanes drawing tasks (ptx_wave.h);
- *                 2 = wave-scheduled with one leaf queue per wave shared by its lanes (ptx_pool.h; default)
+ *                 2 = wave-scheduled with one leaf queue per wave shared by its lanes (ptx_pool.h; default; scenes whose
+ *                 leaves share inorder slots are rendered by pipeline 1 instead)
  *   "compat_rgba8": 1 = also keep the reference's own progressive result: every frame is blended into an RGBA8 target
  *                 exactly as glsl:532-552 + modules/bufferManager.js:18 do (8-bit rounding per frame, the aspect-shifted
  *                 read of the previous target included); read it with ptx_read_compat_rgba8.  0 = off (default)

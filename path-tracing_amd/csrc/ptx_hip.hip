@@ -178,7 +178,7 @@ struct ptx_ctx {
     // counters + timing
     unsigned long long* d_counters = nullptr;
     uint32_t* d_task_counter = nullptr;       // pipeline 2: next undrawn (pixel, frame) task of the running launch
-    int pool_blocks = 0;                       // pipeline 2: waves that are resident at once on this device
+    bool pool_ok = true;                       // pipeline 2 needs disjoint leaf ranges (pair records are addressed by first slot)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<hipEvent_t> free_events;
     double kernel_ms = 0.0;
@@ -498,7 +498,22 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         tris[3 * (size_t)k + 1] = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.f); // glsl:151
         tris[3 * (size_t)k + 2] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.f); // glsl:152
     }
-    for (uint32_t i = 0; i < N; i++) {   // pipeline 2: the leaves' triangles again, two per record, component-interleaved
+    // Pair records live at index first + p, which is only collision-free when the leaves' slot ranges are disjoint (they
+    // partition the inorder list in every tree classes/bvh.js builds).  Arrays that share slots between leaves are still
+    // legal input: such a scene is rendered by pipeline 1, which reads the 48-B records.
+    bool disjoint = true;
+    {
+        std::vector<uint8_t> used(T, 0);
+        for (uint32_t i = 0; i < N && disjoint; i++) {
+            if (sc->node_first[i] == -2) continue;
+            for (int32_t q = 0; q < sc->node_count[i]; q++) {
+                uint8_t& u = used[(size_t)sc->node_first[i] + q];
+                if (u) { disjoint = false; break; }
+                u = 1;
+            }
+        }
+    }
+    for (uint32_t i = 0; i < N && disjoint; i++) {   // pipeline 2: the leaves' triangles again, two per record, component-interleaved
         if (sc->node_first[i] == -2) continue;
         const int32_t first = sc->node_first[i], cnt = sc->node_count[i];
         for (int32_t q = 0; 2 * q < cnt; q++) {
@@ -557,6 +572,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         }
     }
     ctx->S = S;
+    ctx->pool_ok = disjoint;
     ctx->have_scene = true;
     ctx->prim_valid = false;
     return PTX_OK;
@@ -721,7 +737,8 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         const int sel = (opt_prune(ctx) ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
-        if (ctx->opt_pipeline == 2) {
+        const int pipeline = (ctx->opt_pipeline == 2 && !ctx->pool_ok) ? 1 : ctx->opt_pipeline;
+        if (pipeline == 2) {
             switch (sel) {
                 case 0: launch_render_pool<false, false, false>(ctx, nf); break;
                 case 1: launch_render_pool<false, false, true>(ctx, nf); break;
@@ -732,7 +749,7 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
                 case 6: launch_render_pool<true, true, false>(ctx, nf); break;
                 default: launch_render_pool<true, true, true>(ctx, nf); break;
             }
-        } else if (ctx->opt_pipeline == 1) {
+        } else if (pipeline == 1) {
             switch (sel) {
                 case 0: launch_render_wave<false, false, false>(ctx, nf); break;
                 case 1: launch_render_wave<false, false, true>(ctx, nf); break;

@@ -138,6 +138,19 @@ def test_edge_cases(gpu_ctx, ptx, orc):
     # n_frames = 0 is a no-op
     gpu_ctx.render_frames([])
     assert gpu_ctx.frames_done == 1
+    # two leaves that share their slots (legal arrays no builder produces): every pipeline setting still matches the oracle
+    import copy
+    s = copy.deepcopy(ptx.load_scene("my_cornell_6"))
+    leaves = np.nonzero(s.node_first != -2)[0]
+    s.node_first[leaves[3]] = s.node_first[leaves[2]]; s.node_count[leaves[3]] = s.node_count[leaves[2]]
+    p = ptx.config_params("my_cornell_6", 24, 24, 3, 4)
+    gpu_ctx.upload_scene(s); gpu_ctx.set_params(p)
+    want, _ = orc.render_frames(s, p, [1000, 1001])
+    for pipeline in (0, 1, 2):
+        for traversal in (0, 3):
+            gpu_ctx.set_option("pipeline", pipeline); gpu_ctx.set_option("traversal", traversal)
+            gpu_ctx.reset_accum(); gpu_ctx.render_frames([1000, 1001])
+            assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (pipeline, traversal)
 
 
 def collapse_tree(ptx, s, max_depth):
