@@ -234,6 +234,71 @@ static napi_value RenderFrames(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* renderFramesAsync(handle, Int32Array timestamps, firstFrameNumber) -> Promise<undefined>.
+ * The frame loop of the reference is async (main.js:262,391: the page stays responsive while frames render); this is the
+ * counterpart: the frames are queued and awaited on a libuv worker thread, the promise settles on the JS thread.  The
+ * context is not thread-safe: no other call on the same handle until the promise has settled. */
+typedef struct render_job {
+    napi_async_work work;
+    napi_deferred deferred;
+    ptx_ctx *ctx;
+    int32_t *ts;
+    uint32_t n, first;
+    int rc;
+    char msg[600];
+} render_job;
+
+static void render_execute(napi_env env, void *data) {
+    render_job *j = (render_job *)data;
+    (void)env;
+    j->rc = ptx_render_frames(j->ctx, j->ts, j->n, j->first);
+    if (j->rc == PTX_OK) j->rc = ptx_synchronize(j->ctx);
+    if (j->rc) snprintf(j->msg, sizeof j->msg, "ptx status %d: %s", j->rc, ptx_last_error(j->ctx));
+}
+
+static void render_complete(napi_env env, napi_status status, void *data) {
+    render_job *j = (render_job *)data;
+    napi_value v;
+    if (status != napi_ok || j->rc) {
+        napi_value m;
+        napi_create_string_utf8(env, j->rc ? j->msg : "ptx_napi: render job was cancelled", NAPI_AUTO_LENGTH, &m);
+        napi_create_error(env, NULL, m, &v);
+        napi_reject_deferred(env, j->deferred, v);
+    } else {
+        napi_get_undefined(env, &v);
+        napi_resolve_deferred(env, j->deferred, v);
+    }
+    napi_delete_async_work(env, j->work);
+    free(j->ts);
+    free(j);
+}
+
+static napi_value RenderFramesAsync(napi_env env, napi_callback_info info) {
+    napi_value argv[3], promise, name;
+    size_t n = 0;
+    uint32_t first = 0;
+    if (!get_args(env, info, 3, argv)) return NULL;
+    ptx_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    const int32_t *ts = (const int32_t *)get_typed(env, argv[1], napi_int32_array, SIZE_MAX, &n, "timestamps");
+    if (!ts) return NULL;
+    if (napi_get_value_uint32(env, argv[2], &first) != napi_ok) { napi_throw_type_error(env, NULL, "ptx_napi: firstFrameNumber must be an integer"); return NULL; }
+    render_job *j = (render_job *)calloc(1, sizeof *j);
+    if (j) j->ts = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
+    if (!j || !j->ts) { free(j); napi_throw_error(env, NULL, "ptx_napi: out of memory"); return NULL; }
+    memcpy(j->ts, ts, n * sizeof(int32_t));     /* the typed array may be collected before the worker runs */
+    j->ctx = ctx; j->n = (uint32_t)n; j->first = first;
+    if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
+        napi_create_string_utf8(env, "ptx_render_frames", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+        napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok ||
+        napi_queue_async_work(env, j->work) != napi_ok) {
+        free(j->ts); free(j);
+        napi_throw_error(env, NULL, "ptx_napi: cannot queue the render job");
+        return NULL;
+    }
+    return promise;
+}
+
 static napi_value ResetAccum(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
@@ -390,7 +455,7 @@ static napi_value ResetCounters(napi_env env, napi_callback_info info) {
 static napi_value Init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"deviceCount", DeviceCount}, {"create", Create}, {"destroy", Destroy}, {"uploadScene", UploadScene}, {"setParams", SetParams},
-        {"setOption", SetOption}, {"renderFrames", RenderFrames}, {"resetAccum", ResetAccum}, {"framesDone", FramesDone},
+        {"setOption", SetOption}, {"renderFrames", RenderFrames}, {"renderFramesAsync", RenderFramesAsync}, {"resetAccum", ResetAccum}, {"framesDone", FramesDone},
         {"readLinear", ReadLinear}, {"readSum", ReadSum}, {"readRgba8", ReadRgba8}, {"readCompatRgba8", ReadCompatRgba8}, {"writeSum", WriteSum}, {"traceClosest", TraceClosest},
         {"primaryHits", PrimaryHits}, {"counters", Counters}, {"resetCounters", ResetCounters}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

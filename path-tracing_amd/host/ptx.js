@@ -37,6 +37,9 @@ class PathTracer {
   setOption(key, value) { this.addon.setOption(this.handle, key, value); }
   /** timestamps: one int per frame (uniform `timestamp`, main.js:300). Blocks until the frames are done. */
   renderFrames(timestamps, firstFrameNumber) { this.addon.renderFrames(this.handle, Int32Array.from(timestamps), firstFrameNumber || 0); }
+  /** Same, without blocking the event loop (the reference's frame loop is async, main.js:391): resolves when the frames are
+   *  done.  Do not call anything else on this PathTracer until the promise has settled. */
+  renderFramesAsync(timestamps, firstFrameNumber) { return this.addon.renderFramesAsync(this.handle, Int32Array.from(timestamps), firstFrameNumber || 0); }
   resetAccum() { this.addon.resetAccum(this.handle); }
   get framesDone() { return this.addon.framesDone(this.handle); }
   readLinear() { return this.addon.readLinear(this.handle, this.width, this.height); }

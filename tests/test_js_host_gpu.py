@@ -49,6 +49,45 @@ def test_node_cli_checkpoint_resume_and_compat_output(ptx, orc, tmp_path):
     assert open(png, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_node_async_render_matches_sync(tmp_path):
+    """renderFramesAsync (libuv worker, Promise) leaves the event loop free and gives the same bytes as renderFrames."""
+    js = """
+const path = require('path');
+const root = %r;
+const { PathTracer } = require(path.join(root, 'path-tracing_amd/host/ptx'));
+const { readScene } = require(path.join(root, 'path-tracing_amd/host/scenefile'));
+const fs = require('fs');
+const scene = readScene(path.join(root, 'tests/golden/scenes/my_cornell_6.ptxs'));
+const c = JSON.parse(fs.readFileSync(path.join(root, 'tests/golden/scenes/my_cornell_6.json'), 'utf8')).camera;
+const cam = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_right, cameraLeftBottom: c.cam_left_bottom };
+(async () => {
+  const pt = new PathTracer(0);
+  pt.uploadScene(scene); pt.setParams(64, 48, cam, 4, 8);
+  pt.renderFrames([1000, 1001, 1002], 0);
+  const a = pt.readSum();
+  pt.resetAccum();
+  let ticks = 0;
+  const timer = setInterval(() => { ticks++; }, 1);
+  await pt.renderFramesAsync([1000, 1001, 1002], 0);
+  clearInterval(timer);
+  const b = pt.readSum();
+  let same = a.length === b.length;
+  for (let i = 0; same && i < a.length; i++) same = Object.is(a[i], b[i]);
+  let rejected = false;
+  try { await pt.addon.renderFramesAsync(pt.handle, new Float32Array(2), 0); } catch (e) { rejected = true; }
+  console.log(JSON.stringify({ same, frames: pt.framesDone, rejected }));
+  pt.destroy();
+})().catch((e) => { console.error(e); process.exit(1); });
+""" % ROOT
+    f = tmp_path / "async.js"
+    f.write_text(js)
+    import json
+    out = json.loads(subprocess.check_output(["node", str(f)]).decode().strip().splitlines()[-1])
+    assert out == {"same": True, "frames": 3, "rejected": True}
+
+
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
 def test_node_addon_loads_and_fails_loudly_without_gpu():
     import torch
