@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void k_primary(DScene S, DParams P, float* __re
 }
 
 // Test hook: closest hit of arbitrary rays (glsl:207-249), one thread per ray.
-template <bool PRUNE>
+template <bool PRUNE, bool PAIRS>
 __global__ __launch_bounds__(64) void k_trace(DScene S, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
                                               float* __restrict__ t_out, int* __restrict__ tri_out, unsigned long long* counters) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(64) void k_trace(DScene S, const float* __restrict_
     if (i < n) {
         float t; int tri;
         c.rays = c.rays_traced = 1;
-        if (closest_hit<PRUNE, true>(S, mk(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2]),
-                                     mk(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2]), t, tri, c)) c.ray_hits = 1;
+        const V3 ro = mk(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2]), rd = mk(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2]);
+        if (PAIRS ? closest_hit_pairs<PRUNE, true>(S, ro, rd, t, tri, c) : closest_hit<PRUNE, true>(S, ro, rd, t, tri, c)) c.ray_hits = 1;
         t_out[i] = t;
         tri_out[i] = tri;
     }
@@ -901,8 +901,14 @@ extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, u
     if (e == hipSuccess) e = hipMemcpy(d_d, d, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const uint32_t blocks = (n + 63) / 64;
-        if (opt_prune(ctx)) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
-        else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+        const bool pairs = ctx->opt_pipeline == 2 && ctx->pool_ok;      // the arithmetic of the renderer that is selected
+        if (opt_prune(ctx)) {
+            if (pairs) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+            else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+        } else {
+            if (pairs) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

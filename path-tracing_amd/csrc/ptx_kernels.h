@@ -184,6 +184,51 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
     return best < 1.0e38f;
 }
 
+// The same query with pipeline 2's arithmetic building blocks, one ray per lane and nothing deferred: entry-first slab test
+// on the octant layouts (slab_node_ordered, rays with an infinite 1/d component excepted) and two triangles per step from
+// the pair records (tri_test2).  ptx_trace_closest uses it when pipeline 2 is selected, so known-answer rays around the
+// shader's epsilons go through exactly the code the default renderer runs.
+template <bool PRUNE, bool COUNT>
+__device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, float& out_t, int& out_tri, LocalCnt& c) {
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const bool ordered = S.oct_stride != 0u && fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff();
+    float best = 1.0e38f, limit = 3.0e38f;
+    uint32_t best_k = 0xFFFFFFFFu;
+    uint32_t i = 0;
+    const uint32_t N = (uint32_t)S.N;
+    const uint32_t nbase = octant(d) * S.oct_stride;
+    while (i < N) {
+        const float4 a = ld16(S.nodes, nbase + (i << 5));
+        const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
+        if (COUNT) c.node_visits++;
+        float tn;
+        bool hit = ordered ? slab_node_ordered(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn);
+        if (PRUNE) hit = hit && !(tn > limit);
+        if (!hit) { i = (uint32_t)__float_as_int(b.z); continue; }
+        i++;
+        const int fc = __float_as_int(b.w);
+        if (fc < 0) continue;                                  // inner node (or empty leaf)
+        uint32_t k = (uint32_t)fc & 0x00FFFFFFu, pbyte = k * 80u;
+        for (;;) {
+            const float4 r0 = ld16(S.pairs, pbyte), r1 = ld16(S.pairs, pbyte + 16u), r2 = ld16(S.pairs, pbyte + 32u),
+                         r3 = ld16(S.pairs, pbyte + 48u), r4 = ld16(S.pairs, pbyte + 64u);
+            const int rem = __float_as_int(r4.z);
+            bool hA, hB;
+            float tA, tB;
+            tri_test2(o, d, r0, r1, r2, r3, r4, hA, hB, tA, tB);
+            if (COUNT) c.tri_tests += rem >= 2 ? 2u : 1u;
+            if (hA && (tA < best || (tA == best && k < best_k))) { best = tA; best_k = k; }
+            if (hB && (tB < best || (tB == best && k + 1u < best_k))) { best = tB; best_k = k + 1u; }
+            if (rem <= 2) break;
+            k += 2u; pbyte += 80u;
+        }
+        if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+    }
+    out_t = best;
+    out_tri = best < 1.0e38f ? __float_as_int(ld16(S.tris, best_k * 48u).w) : -1;
+    return best < 1.0e38f;
+}
+
 // glsl:501-514 + 145-148: primary ray direction of pixel (px, py), GL origin (bottom-left).
 __device__ __forceinline__ V3 primary_dir(const DParams& P, uint32_t px, uint32_t py) {
     float u = ((float)px + 0.5f) / (float)P.W;

@@ -59,8 +59,9 @@ def random_rays(s, n, seed):
 
 @pytest.mark.parametrize("name", SCENES)
 @pytest.mark.parametrize("traversal", [0, 1, 2, 3])
-def test_trace_closest_bit_exact(gpu_ctx, ptx, orc, name, traversal):
-    s, _ = setup(gpu_ctx, ptx, name, 8, 8, traversal=traversal)
+@pytest.mark.parametrize("pipeline", [0, 2])          # 0: 48-B records + scalar test; 2: pair records, packed math, ordered slabs
+def test_trace_closest_bit_exact(gpu_ctx, ptx, orc, name, traversal, pipeline):
+    s, _ = setup(gpu_ctx, ptx, name, 8, 8, traversal=traversal, pipeline=pipeline)
     o, d = random_rays(s, 20000, 7)
     t_g, tri_g = gpu_ctx.trace_closest(o, d)
     t_o, tri_o, c = orc.trace_closest(s, o, d)
@@ -74,6 +75,68 @@ def test_trace_closest_bit_exact(gpu_ctx, ptx, orc, name, traversal):
         assert k["tri_tests"] == c["tri_tests"]
     else:
         assert k["tri_tests"] <= c["tri_tests"]
+
+
+def epsilon_scene(ptx):
+    """A hand-made scene around the shader's epsilons: a quad of two triangles sharing an edge, the same quad
+    again (coincident duplicates: ties on t go to the earlier inorder slot), a triangle whose doubled area is ~1e-4 (the
+    absolute determinant cut-off of glsl:156 makes it visible only head-on) and one far below it (never visible).
+    Two leaves under one root; slots in an order that differs from the triangle numbering."""
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [1, 1, 0]], [[0, 0, 0], [1, 1, 0], [0, 1, 0]],             # quad z = 0
+                    [[0, 0, 0], [1, 0, 0], [1, 1, 0]], [[0, 0, 0], [1, 1, 0], [0, 1, 0]],             # the same quad again
+                    [[2, 0, 0], [2.0101, 0, 0], [2, 0.0100, 0]],                                      # 2A = 1.01e-4
+                    [[2, 1, 0], [2.005, 1, 0], [2, 1.005, 0]],                                        # 2A = 2.5e-5: invisible
+                    [[-1, -1, -2], [3, -1, -2], [1, 3, -2]]], dtype=np.float32)                       # big backdrop z = -2
+    T = len(tri)
+    order = np.array([3, 1, 4, 0, 2, 6, 5], dtype=np.int32)                                            # inorder slots -> triangle ids
+    lo = [tri[order[:4]].reshape(-1, 3).min(0), tri[order[4:]].reshape(-1, 3).min(0)]
+    hi = [tri[order[:4]].reshape(-1, 3).max(0), tri[order[4:]].reshape(-1, 3).max(0)]
+    nmin = np.array([np.minimum(lo[0], lo[1]), lo[0], lo[1]], dtype=np.float32)
+    nmax = np.array([np.maximum(hi[0], hi[1]), hi[0], hi[1]], dtype=np.float32)
+    z = np.zeros(3 * T, dtype=np.float32)
+    return ptx.scene.Scene(T=T, N=3, L=0, coords=np.ascontiguousarray(tri.reshape(-1)), normals=np.tile(np.float32([0, 0, 1]), T), colors=z + 1, emissions=z,
+                           light_tri=np.zeros(0, dtype=np.int32), node_min=nmin.reshape(-1), node_max=nmax.reshape(-1),
+                           node_miss=np.array([-1, 2, -1], dtype=np.int32), node_first=np.array([-2, 0, 4], dtype=np.int32),
+                           node_count=np.array([0, 4, 3], dtype=np.int32), inorder_tri=order)
+
+
+@pytest.mark.parametrize("pipeline", [0, 2])
+def test_epsilon_rays(gpu_ctx, ptx, orc, pipeline):
+    s = epsilon_scene(ptx)
+    s.validate()
+    rng = np.random.default_rng(11)
+    o, d = [], []
+    def ray(origin, target):
+        v = np.asarray(target, dtype=np.float64) - np.asarray(origin, dtype=np.float64)
+        o.append(origin); d.append(v / np.linalg.norm(v))
+    for _ in range(3000):                                       # the shared edge / the diagonal / the outer edges and corners, exactly
+        a = rng.random()
+        ray([0.3, 0.2, 1.5], [a, a, 0]); ray([a, a, 0.75], [a, a, 0]); ray([a, 0.1, 2.0], [a, 0, 0]); ray([0.5, 0.5, 1.0], [round(a), round(rng.random()), 0])
+    for _ in range(3000):                                       # t around 1e-4: origins a hair above the quad
+        x, y = rng.random(2)
+        h = np.float32(1e-4) * (0.5 + rng.random())
+        ray([x, y, h], [x + 1e-6 * rng.standard_normal(), y, -1])
+    for _ in range(6000):                                       # |a| around 1e-4: the small triangles from every tilt
+        c = rng.random(2) * 0.004 + [2.001, 0.001] if rng.random() < 0.7 else rng.random(2) * 0.002 + [2.0005, 1.0005]
+        th, ph = np.arccos(rng.random()), 2 * np.pi * rng.random()
+        dirv = np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+        ray(np.array([c[0], c[1], 0]) + dirv * (0.5 + rng.random()), [c[0], c[1], 0])
+    for ax in range(3):                                         # axis-parallel rays: 1/d = inf, NaN slabs on bounding planes
+        for _ in range(300):
+            p0 = rng.random(3) * [3, 2, 3] - [0.5, 0.5, 1.0]
+            p0[rng.integers(3)] = rng.choice([0.0, 1.0, 2.0, -2.0, -1.0, 3.0])
+            dv = np.zeros(3); dv[ax] = rng.choice([-1.0, 1.0])
+            o.append(p0); d.append(dv)
+    o = np.asarray(o, dtype=np.float32); d = np.asarray(d, dtype=np.float32)
+    t_o, tri_o, _ = orc.trace_closest(s, o, d)
+    small = (tri_o == 4).sum()
+    # duplicates: triangle 3 (slot 0) always beats its twin 1 (slot 1); the ~1e-4 triangle shows only head-on; the 2.5e-5 one never
+    assert 0 < small < 4200 and (tri_o == 5).sum() == 0 and (tri_o == 1).sum() == 0 and (tri_o == 0).sum() > 500 and (tri_o == 3).sum() > 500
+    gpu_ctx.upload_scene(s)
+    for traversal in (0, 1, 2, 3):
+        gpu_ctx.set_option("traversal", traversal); gpu_ctx.set_option("pipeline", pipeline)
+        t_g, tri_g = gpu_ctx.trace_closest(o, d)
+        assert (tri_g == tri_o).all() and (bits(t_g) == bits(t_o)).all(), traversal
 
 
 def test_trace_closest_empty_and_single(gpu_ctx, ptx, orc):
