@@ -415,6 +415,8 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n
         items.push_back(it);
     }
     if (items.empty()) return false;
+    // the kernels address node records with 32-bit byte offsets: 8 layouts x (2 * leaves - 1) nodes x 32 B must stay below 4 GiB
+    if ((uint64_t)items.size() * 2u * 32u * 8u >= (1ull << 32)) return false;
     std::vector<uint32_t> ids(items.size());
     for (uint32_t q = 0; q < ids.size(); q++) ids[q] = q;
     std::vector<SahNode> tree;
