@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                                                     const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
                                                     float4* __restrict__ fb, uint32_t n_frames, uint32_t chunk,
                                                     uint32_t* __restrict__ task_counter, unsigned long long* counters) {
-    __shared__ float lds[PW_C_SAMPLES * 64];         // path state only: the work counters are wave totals in wcnt[]
+    __shared__ float lds[PW_C_SAMPLES * 64];         // path state only (25 words per lane); work counters live in scalar registers
     __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
     __shared__ uint2 queue[PTX_POOL_QCAP];
     const uint32_t lane = threadIdx.x;
