@@ -29,6 +29,10 @@
 #define PTX_POOL_WALK_KEEP 0     // leave a WALK phase early once no more than KEEP/8 of the lanes it started with still walk
 #endif
 
+#ifndef PTX_POOL_TRI_PRIO
+#define PTX_POOL_TRI_PRIO 3      // s_setprio of a wave while it runs a TRI phase (0 elsewhere)
+#endif
+
 #ifndef PTX_POOL_MIN_WAVES
 #define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
 #endif
@@ -93,6 +97,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
         unsigned long long t_ph = 0;
         if (COUNT) t_ph = __builtin_amdgcn_s_memtime();
 
+        // TRI phases are load-latency bound (five 16-B loads, then one burst of packed math): their instructions go first
+        if (phase == 1) __builtin_amdgcn_s_setprio(PTX_POOL_TRI_PRIO); else __builtin_amdgcn_s_setprio(0);
         if (phase == 0) {
             if (PRUNE) limit = __uint_as_float((uint32_t)(keys[lane] >> 32)) * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
