@@ -178,6 +178,7 @@ struct ptx_ctx {
     // counters + timing
     unsigned long long* d_counters = nullptr;
     uint32_t* d_task_counter = nullptr;       // pipeline 2: next undrawn (pixel, frame) task of the running launch
+    uint64_t pool_resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pipeline 2: grid size per kernel variant (queried once)
     bool pool_ok = true;                       // pipeline 2 needs disjoint leaf ranges (pair records are addressed by first slot)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<hipEvent_t> free_events;
@@ -689,10 +690,13 @@ static void launch_render_pool(ptx_ctx* ctx, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
     const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32 - 2^28: ptx_render_frames caps the batch
     const uint32_t chunk = (uint32_t)ctx->opt_pool_chunk;
-    int per_cu = 0, cus = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64, 0);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint64_t resident = (uint64_t)std::max(1, per_cu) * (uint64_t)std::max(1, cus);
+    uint64_t& resident = ctx->pool_resident[(PRUNE ? 4 : 0) | (MEMO ? 2 : 0) | (COUNT ? 1 : 0)];   // waves one residency of the chip holds
+    if (resident == 0) {
+        int per_cu = 0, cus = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64, 0);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        resident = (uint64_t)std::max(1, per_cu) * (uint64_t)std::max(1, cus);
+    }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident, (total + chunk - 1) / chunk);
     (void)hipMemsetAsync(ctx->d_task_counter, 0, sizeof(uint32_t), ctx->stream);
     hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
