@@ -382,7 +382,7 @@ def test_error_behaviour(ptx):
 
 # ---------------------------------------------------------------- BASELINE.json's full sizes: properties + oracle row samples
 
-@pytest.mark.parametrize("cfg", ["C2", "C4", "headline"])
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4", "headline", "C5"])
 def test_full_size_properties(gpu_ctx, ptx, orc, cfg):
     c = ptx.CONFIGS[cfg]
     s, p = setup(gpu_ctx, ptx, c["scene"], c["width"], c["height"], spp=c["sample_count"], bounces=c["max_path_length"])
