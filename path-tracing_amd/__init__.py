@@ -10,4 +10,4 @@ The product host is JavaScript (host/*.js + the raw N-API addon in csrc/ptx_napi
 """
 from .scene import Scene, Params, load_scene, load_camera, config_params, CONFIGS  # noqa: F401
 from .binding import Context, PtxError, lib_path, load_library  # noqa: F401
-from .distributed import frames_for_rank, allreduce_sum  # noqa: F401
+from .distributed import frames_for_rank, allreduce_sum, render_frames_distributed  # noqa: F401

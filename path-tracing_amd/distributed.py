@@ -21,3 +21,62 @@ def allreduce_sum(tensor, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
     return tensor
+
+
+def render_frames_distributed(ctx, timestamps, batch=None, on_batch=None, group=None):
+    """Renders `timestamps` (the whole job's frame list, identical on every rank) split by frame over the ranks of the
+    process group, on this rank's `Context` ctx, and leaves the SUM OVER ALL RANKS in every rank's accumulation buffer
+    (ctx.read_sum() / read_linear() / read_rgba8() then give the same image everywhere).  ctx must start from a reset
+    accumulation.  Counterpart of the reference's progressive loop (main.js:391-436) for G GPUs:
+
+      batch    : frames each rank renders between two progress points (None: all of its frames in one go)
+      on_batch : callback(sum_tensor, frames_done_all_ranks) after every batch with the all-reduced running sum, a
+                 (H, W, 4) float32 tensor on ctx's device -- a preview or checkpoint hook; the per-rank accumulation is
+                 not touched by it, so previews cost one extra all-reduce each and change no result.
+
+    One all-reduce of W*H*4 floats per progress point and one at the end; with backend "nccl" it runs over RCCL on the
+    device buffer, with any other backend (gloo in rehearsals) the buffer is staged through the host.
+    Returns the total number of frames accumulated."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    ts = np.ascontiguousarray(timestamps, dtype=np.int32)
+    mine = frames_for_rank(len(ts), rank, world)
+    dev = torch.device("cuda", ctx.device)
+    buf = torch.zeros(ctx.params.height, ctx.params.width, 4, dtype=torch.float32, device=dev)
+    on_device = multi and dist.get_backend(group) == "nccl"
+
+    def reduce_into_buf():
+        ctx.accum_export_device(buf.data_ptr())
+        ctx.synchronize()
+        done = torch.tensor([ctx.frames_done], dtype=torch.int64, device=dev if on_device else "cpu")
+        if multi:
+            if on_device:
+                dist.all_reduce(buf, group=group)
+            else:
+                h = buf.cpu()
+                dist.all_reduce(h, group=group)
+                buf.copy_(h)
+            dist.all_reduce(done, group=group)
+            torch.cuda.synchronize(dev)
+        return int(done.item())
+
+    # every rank goes through the same number of progress points, also when the frames do not divide evenly
+    most = (len(ts) + world - 1) // world                      # frames of the busiest rank
+    step = most if not batch else max(1, int(batch))
+    rounds = 1 if step <= 0 else max(1, -(-most // step))
+    total = 0
+    for r in range(rounds):
+        part = mine[r * step:(r + 1) * step] if step > 0 else []
+        if len(part):
+            ctx.render_frames(ts[part], first_frame_number=int(part[0]))
+        if on_batch is not None or r == rounds - 1:
+            total = reduce_into_buf()
+            if on_batch is not None:
+                on_batch(buf, total)
+    ctx.accum_import_device(buf.data_ptr(), total)
+    ctx.synchronize()
+    return total

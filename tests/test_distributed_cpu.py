@@ -48,3 +48,43 @@ def test_two_rank_frame_split_equals_single_process(ptx, orc, tmp_path):
     want, _ = orc.render_frames(s, p, ptx.scene.timestamps(n_frames), nthreads=1)
     # same frames, different float-add association: a few ulp of the sum (values in [0, n_frames])
     assert np.abs(got - want).max() <= 4 * np.finfo(np.float32).eps * n_frames
+
+
+def _gpu_worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share cuda:0; the buffer is staged through the host
+    import ptx_import
+    m = ptx_import.load()
+    s = m.load_scene("my_cornell_6")
+    p = m.config_params("my_cornell_6", 40, 24, 3, 4)
+    ctx = m.Context(0)
+    ctx.upload_scene(s); ctx.set_params(p)
+    seen = []
+    total = m.render_frames_distributed(ctx, m.scene.timestamps(n_frames), batch=2, on_batch=lambda buf, n: seen.append((n, float(buf[..., :3].sum()))))
+    np.save(os.path.join(out_dir, f"sum{rank}.npy"), ctx.read_sum())
+    np.save(os.path.join(out_dir, f"seen{rank}.npy"), np.asarray(seen, dtype=np.float64))
+    assert total == n_frames and ctx.frames_done == n_frames
+    ctx.close()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_render_frames_distributed_two_ranks_one_gpu(ptx, gpu_ctx, tmp_path):
+    """render_frames_distributed: 5 frames over 2 ranks in progress batches of 2 == one process rendering all 5."""
+    n_frames, world = 5, 2
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_gpu_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
+    s = ptx.load_scene("my_cornell_6")
+    p = ptx.config_params("my_cornell_6", 40, 24, 3, 4)
+    gpu_ctx.upload_scene(s); gpu_ctx.set_params(p); gpu_ctx.reset_accum()
+    gpu_ctx.render_frames(ptx.scene.timestamps(n_frames))
+    want = gpu_ctx.read_sum()
+    a, b = np.load(tmp_path / "sum0.npy"), np.load(tmp_path / "sum1.npy")
+    assert (a.view(np.uint32) == b.view(np.uint32)).all()                      # every rank ends with the same buffer
+    assert np.abs(a - want).max() <= 4 * np.finfo(np.float32).eps * n_frames   # float-add association only
+    seen = np.load(tmp_path / "seen0.npy")
+    assert [int(x) for x in seen[:, 0]] == [4, 5] and seen[0, 1] < seen[1, 1]  # previews: 2 + 2 frames, then all 5
