@@ -693,9 +693,9 @@ static void launch_render_pool(ptx_ctx* ctx, uint32_t nf) {
     uint64_t& resident = ctx->pool_resident[(PRUNE ? 4 : 0) | (MEMO ? 2 : 0) | (COUNT ? 1 : 0)];   // waves one residency of the chip holds
     if (resident == 0) {
         int per_cu = 0, cus = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64, 0);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        resident = (uint64_t)std::max(1, per_cu) * (uint64_t)std::max(1, cus);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+        resident = (uint64_t)per_cu * (uint64_t)cus;   // any value is correct (waves draw work until none is left); this one fills the chip
     }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident, (total + chunk - 1) / chunk);
     (void)hipMemsetAsync(ctx->d_task_counter, 0, sizeof(uint32_t), ctx->stream);
