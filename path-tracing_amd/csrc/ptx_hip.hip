@@ -218,6 +218,8 @@ extern "C" int ptx_device_count(void) {
 
 extern "C" const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+extern "C" void ptx_destroy(ptx_ctx* ctx);
+
 extern "C" ptx_ctx* ptx_create(const int* device_ids, int n_devices) {
     if (!device_ids || n_devices != 1) {
         g_create_error = "ptx_create: exactly one device per context (multi-GPU = one context per GPU)";
@@ -249,7 +251,7 @@ extern "C" ptx_ctx* ptx_create(const int* device_ids, int n_devices) {
         (e = hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc(&ctx->d_task_counter, sizeof(uint32_t))) != hipSuccess) {
         g_create_error = std::string("ptx_create: ") + hipGetErrorString(e);
-        delete ctx;
+        ptx_destroy(ctx);                  // releases whatever was created before the failing call
         return nullptr;
     }
     return ctx;
@@ -740,6 +742,10 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
         // pageable source: the runtime stages the copy before returning, so the caller's array is free to go
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ts, timestamps + f0, nf * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->pending_events.size() >= 64) {   // a caller that never synchronises: keep the event list bounded
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            drain_events(ctx);
+        }
         hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
         const int sel = (opt_prune(ctx) ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
