@@ -42,9 +42,81 @@ CASES = {
 }
 
 
+# name: (scene fixture, W, H): primary-ray words (hit triangle id, t bits, direction bits) from a DERIVED debug shader
+PRIM_CASES = {
+    "my_cornell_6_prim": ("my_cornell_6", 64, 36),
+    "my_cornell_6_tall_prim": ("my_cornell_6", 24, 40),
+    "cornell_prim": ("cornell", 40, 40),
+    "bedroom2_v5_prim": ("bedroom2_v5", 48, 27),
+    "teapot_prim": ("teapot", 48, 27),
+    "pixar_room_prim": ("pixar_room", 64, 36),
+}
+PRIM_OUT = os.path.join(ROOT, "tests", "golden", "ref_prim")
+
+
+def derive_debug_shader(text):
+    """The reference fragment shader with three additions: a global that remembers the inorder triangle
+    index of the current best hit inside ray_bvh_intersection_hit_miss, a uniform debugWord, and a tail of main() that
+    traces the primary ray once more and writes one 32-bit word (triangle id / t bits / direction bits) as four bytes.
+    Everything the words depend on -- ray generation, traversal, both intersection routines -- is the reference's text.
+    Built in memory from /root/reference at run time; never stored."""
+    def sub_once(t, old, new):
+        assert t.count(old) == 1, (t.count(old), old)
+        return t.replace(old, new)
+    text = sub_once(text, "bool ray_bvh_intersection_hit_miss(out float out_t, out Triangle out_triangle, vec3 origin, vec3 direction) {",
+                    "int g_hitIndex = -1;\nuniform int debugWord;\nbool ray_bvh_intersection_hit_miss(out float out_t, out Triangle out_triangle, vec3 origin, vec3 direction) {")
+    text = sub_once(text, "            // outColor = vec4(0.0f, 1.0f, 0.0f, 1.0f);\n            out_t = t;\n            out_triangle = triangle;",
+                    "            out_t = t;\n            out_triangle = triangle;\n            g_hitIndex = triangleIndex;")
+    tail = ("  {\n    float dbg_t; Triangle dbg_tri; g_hitIndex = -1;\n"
+            "    ray_bvh_intersection_hit_miss(dbg_t, dbg_tri, cameraSource, ray_direction);\n"
+            "    uint w = debugWord == 0 ? uint(g_hitIndex) : (debugWord == 1 ? floatBitsToUint(dbg_t) : floatBitsToUint(ray_direction[debugWord - 2]));\n"
+            "    outColor = vec4(float(w & 255u), float((w >> 8) & 255u), float((w >> 16) & 255u), float(w >> 24)) / 255.0f;\n  }\n")
+    head, sep, rest = text.rpartition("  outColor = vec4(blendedColor.rgb, 1.0f);\n")
+    assert sep, "main()'s final store not found"
+    return head + sep + tail + rest
+
+
+def run_prim_case(name):
+    m = ptx_import.load()
+    scene_name, w, h = PRIM_CASES[name]
+    s = m.load_scene(scene_name)
+    cam = m.load_camera(scene_name)
+    f32 = lambda v: [float(np.float32(x)) for x in v]  # noqa: E731
+    payload = {
+        "width": w, "height": h, "sample_count": 1, "max_path_length": 0, "timestamps": [1000], "debug_words": [0, 1, 2, 3, 4],
+        "cam_src": f32(cam["cam_src"]), "cam_dir": f32(cam["cam_dir"]), "cam_up": f32(cam["cam_up"]),
+        "cam_right": f32(cam["cam_right"]), "cam_left_bottom": f32(cam["cam_left_bottom"]),
+        "vertexShader": open(os.path.join(REF, "vertexShader.glsl")).read(),
+        "fragmentShader": derive_debug_shader(open(os.path.join(REF, "fragmentShaderPathTracing.glsl")).read()),
+        "scene": {"T": s.T, "N": s.N, "L": s.L, **{k: getattr(s, k).tolist() for k in
+                  ("coords", "normals", "colors", "emissions", "light_tri", "node_min", "node_max", "node_miss", "node_first", "node_count", "inorder_tri")}},
+    }
+    res = call_harness(name, payload)
+    words = [np.frombuffer(base64.b64decode(b), dtype="<u4").reshape(h, w) for b in res["frames"]]
+    os.makedirs(PRIM_OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(PRIM_OUT, name + ".npz"), tri=words[0].view(np.int32), t_bits=words[1], dir_bits=np.stack(words[2:5], axis=-1),
+                        scene=scene_name, width=w, height=h, renderer=json.dumps(res["info"]))
+    print(name, res["info"], "hits", int((words[0].view(np.int32) >= 0).sum()), "of", w * h, flush=True)
+
+
 def kaleido_exe():
     import kaleido
     return os.path.join(os.path.dirname(kaleido.__file__), "executable", "kaleido")
+
+
+def call_harness(name, payload):
+    req = {"data": {"data": [{"type": "scatter", "customdata": [payload]}], "layout": {}}, "format": "json", "width": 16, "height": 16, "scale": 1}
+    cmd = [kaleido_exe(), "plotly", "--plotlyjs=" + os.path.join(ROOT, "oracle", "webgl_harness.js"), "--no-sandbox", "--disable-gpu",
+           "--single-process", "--disable-breakpad"]
+    proc = subprocess.run(cmd, input=(json.dumps(req) + "\n").encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=7200)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    reply = json.loads(lines[-1])
+    res = reply.get("result")
+    if isinstance(res, str):
+        res = json.loads(res)
+    if not res or "error" in res:
+        raise RuntimeError(f"{name}: harness failed: {reply} / {proc.stderr.decode(errors='replace')[-500:]}")
+    return res
 
 
 def run_case(name):
@@ -62,18 +134,8 @@ def run_case(name):
         "scene": {"T": s.T, "N": s.N, "L": s.L, **{k: getattr(s, k).tolist() for k in
                   ("coords", "normals", "colors", "emissions", "light_tri", "node_min", "node_max", "node_miss", "node_first", "node_count", "inorder_tri")}},
     }
-    req = {"data": {"data": [{"type": "scatter", "customdata": [payload]}], "layout": {}}, "format": "json", "width": 16, "height": 16, "scale": 1}
-    cmd = [kaleido_exe(), "plotly", "--plotlyjs=" + os.path.join(ROOT, "oracle", "webgl_harness.js"), "--no-sandbox", "--disable-gpu",
-           "--single-process", "--disable-breakpad"]
     t0 = time.time()
-    proc = subprocess.run(cmd, input=(json.dumps(req) + "\n").encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=7200)
-    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.strip()]
-    reply = json.loads(lines[-1])
-    res = reply.get("result")
-    if isinstance(res, str):
-        res = json.loads(res)
-    if not res or "error" in res:
-        raise RuntimeError(f"{name}: harness failed: {reply} / {proc.stderr.decode(errors='replace')[-500:]}")
+    res = call_harness(name, payload)
     frames = np.stack([np.frombuffer(base64.b64decode(b), dtype=np.uint8).reshape(h, w, 4) for b in res["frames"]])
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), frames=frames, scene=scene_name, width=w, height=h, sample_count=spp,
@@ -83,5 +145,5 @@ def run_case(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES)):
-        run_case(n)
+    for n in (sys.argv[1:] or list(CASES) + list(PRIM_CASES)):
+        run_prim_case(n) if n in PRIM_CASES else run_case(n)

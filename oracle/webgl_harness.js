@@ -121,11 +121,15 @@
     gl.vertexAttribPointer(loc, 2, gl.FLOAT, false, 0, 0);
 
     var frames = [], times = [];
-    for (var f = 0; f < p.timestamps.length; f++) {
+    // p.debug_words: a DERIVED shader (built by gen_ref_frames.py from the reference text at run time) writes one 32-bit word
+    // per pixel as four bytes; one draw per word, selected by the uniform debugWord
+    var nDraws = p.debug_words ? p.debug_words.length : p.timestamps.length;
+    for (var f = 0; f < nDraws; f++) {
+      if (p.debug_words) gl.uniform1i(U('debugWord'), p.debug_words[f]);
       // default: frameNumber = 0 for every frame: blend factor 1 => the un-blended per-frame image (SURVEY.md 8c-1
       // "Limits"); p.progressive: frameNumber = f, the reference's running blend through the 8-bit targets
       var n = p.progressive ? f : 0;
-      gl.uniform1i(U('timestamp'), p.timestamps[f]);
+      gl.uniform1i(U('timestamp'), p.timestamps[p.debug_words ? 0 : f]);
       gl.uniform1i(U('frameNumber'), n);
       gl.activeTexture(gl.TEXTURE0); gl.bindTexture(gl.TEXTURE_2D, tex[(n + 1) % 2]);
       gl.uniform1i(U('previousFrameTexture'), 0);

@@ -101,3 +101,52 @@ def test_gpu_matches_reference_shader(ptx, gpu_ctx, case):
             gpu_ctx.render_frames([int(ts)])
             frames.append(gpu_ctx.read_rgba8(apply_gamma=False, flip_y=False))   # == the reference's RGBA8 target at frameNumber 0
     check(case, frames, ref)
+
+
+# ---------------------------------------------------------------- primary-ray words from the derived debug shader (ref_prim/)
+# Hit triangle id, bits of t and bits of the ray direction of every pixel, written by the reference's own ray generation,
+# traversal and intersection code (oracle/gen_ref_frames.py derive_debug_shader adds only the word dump).  Integer / bit
+# parity, so the bar is equality; pixels where SwiftShader itself disagrees would be listed as documented ties (none).
+PRIM = os.path.join(os.path.dirname(__file__), "golden", "ref_prim")
+PRIM_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(PRIM, "*.npz")))
+
+
+def load_prim(ptx, case):
+    z = np.load(os.path.join(PRIM, case + ".npz"))
+    name = str(z["scene"])
+    return z, ptx.load_scene(name), ptx.config_params(name, int(z["width"]), int(z["height"]))
+
+
+def test_prim_fixtures_present():
+    assert {"my_cornell_6_prim", "my_cornell_6_tall_prim", "pixar_room_prim", "teapot_prim"} <= set(PRIM_CASES)
+
+
+@pytest.mark.parametrize("case", PRIM_CASES)
+def test_oracle_primary_words_match_reference_shader(ptx, orc, case):
+    z, s, p = load_prim(ptx, case)
+    assert "SwiftShader" in str(z["renderer"])
+    assert (orc.primary_dirs(p).view(np.uint32) == z["dir_bits"]).all()
+    t, tri, _ = orc.primary_hits(s, p)
+    assert (tri == z["tri"]).all() and (t.view(np.uint32) == z["t_bits"]).all()
+    assert (z["tri"] >= 0).sum() > 0.3 * z["tri"].size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", PRIM_CASES)
+def test_gpu_primary_words_match_reference_shader(ptx, gpu_ctx, case):
+    z, s, p = load_prim(ptx, case)
+    gpu_ctx.upload_scene(s)
+    gpu_ctx.set_params(p)
+    assert (gpu_ctx.primary_dirs().view(np.uint32) == z["dir_bits"]).all()
+    for traversal in (0, 1, 2, 3):
+        gpu_ctx.set_option("traversal", traversal)
+        t, tri = gpu_ctx.primary_hits()
+        assert (tri == z["tri"]).all() and (t.view(np.uint32) == z["t_bits"]).all(), traversal
+    # the same rays through ptx_trace_closest with the default renderer's arithmetic (pair records, ordered slabs)
+    d = gpu_ctx.primary_dirs().reshape(-1, 3)
+    o = np.tile(np.asarray(p.cam_src, dtype=np.float32), (d.shape[0], 1))
+    for pipeline in (0, 2):
+        gpu_ctx.set_option("pipeline", pipeline)
+        t, tri = gpu_ctx.trace_closest(o, d)
+        assert (tri.reshape(z["tri"].shape) == z["tri"]).all() and (t.view(np.uint32).reshape(z["tri"].shape) == z["t_bits"]).all(), pipeline
+    gpu_ctx.set_option("pipeline", 2)
