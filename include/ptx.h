@@ -115,7 +115,10 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 leaves share inorder slots are rendered by pipeline 1 instead)
  *   "compat_rgba8": 1 = also keep the reference's own progressive result: every frame is blended into an RGBA8 target
  *                 exactly as glsl:532-552 + modules/bufferManager.js:18 do (8-bit rounding per frame, the aspect-shifted
- *                 read of the previous target included); read it with ptx_read_compat_rgba8.  0 = off (default)
+ *                 read of the previous target included); read it with ptx_read_compat_rgba8.  0 = off (default).
+ *                 GL leaves the target's float -> 8-bit store and the texel chosen on an exact texel boundary to the
+ *                 implementation: 1 uses the preferred rules (round to nearest; floor), 2 those of SwiftShader, the
+ *                 implementation behind tests/golden/ref_frames, whose frames it reproduces byte for byte
  *   "frame_batch": max frames rendered concurrently (0 = auto)
  *   "tasks_per_wave": (pixel, frame) tasks one wave of pipeline 1 works through (default 128)
  *   "pool_chunk": pipeline 2 runs one chip residency of persistent waves; each draws this many tasks at a time from a

@@ -52,6 +52,14 @@ PRIM_CASES = {
     "pixar_room_prim": ("pixar_room", 64, 36),
 }
 PRIM_OUT = os.path.join(ROOT, "tests", "golden", "ref_prim")
+# name: (scene fixture, W, H, sample_count, timestamp): float bits of the frame's clamp(mean radiance) (glsl:516-529) at
+# maxPathLength = 1, where no result depends on sin/cos: the whole shading arithmetic, bit for bit
+RAD_CASES = {
+    "my_cornell_6_rad_b1": ("my_cornell_6", 48, 48, 8, 1000),
+    "my_cornell_6_tall_rad_b1": ("my_cornell_6", 24, 40, 4, 1001),
+    "bedroom2_v5_rad_b1": ("bedroom2_v5", 48, 27, 4, 1000),
+    "pixar_room_rad_b1": ("pixar_room", 48, 27, 4, 1000),
+}
 
 
 def derive_debug_shader(text):
@@ -69,7 +77,7 @@ def derive_debug_shader(text):
                     "            out_t = t;\n            out_triangle = triangle;\n            g_hitIndex = triangleIndex;")
     tail = ("  {\n    float dbg_t; Triangle dbg_tri; g_hitIndex = -1;\n"
             "    ray_bvh_intersection_hit_miss(dbg_t, dbg_tri, cameraSource, ray_direction);\n"
-            "    uint w = debugWord == 0 ? uint(g_hitIndex) : (debugWord == 1 ? floatBitsToUint(dbg_t) : floatBitsToUint(ray_direction[debugWord - 2]));\n"
+            "    uint w = debugWord == 0 ? uint(g_hitIndex) : (debugWord == 1 ? floatBitsToUint(dbg_t) : (debugWord < 5 ? floatBitsToUint(ray_direction[debugWord - 2]) : floatBitsToUint(currentColor[debugWord - 5])));\n"
             "    outColor = vec4(float(w & 255u), float((w >> 8) & 255u), float((w >> 16) & 255u), float(w >> 24)) / 255.0f;\n  }\n")
     head, sep, rest = text.rpartition("  outColor = vec4(blendedColor.rgb, 1.0f);\n")
     assert sep, "main()'s final store not found"
@@ -78,12 +86,14 @@ def derive_debug_shader(text):
 
 def run_prim_case(name):
     m = ptx_import.load()
-    scene_name, w, h = PRIM_CASES[name]
+    rad = name in RAD_CASES
+    scene_name, w, h = (RAD_CASES[name] if rad else PRIM_CASES[name])[:3]
+    spp, ts0 = (RAD_CASES[name][3:] if rad else (1, 1000))
     s = m.load_scene(scene_name)
     cam = m.load_camera(scene_name)
     f32 = lambda v: [float(np.float32(x)) for x in v]  # noqa: E731
     payload = {
-        "width": w, "height": h, "sample_count": 1, "max_path_length": 0, "timestamps": [1000], "debug_words": [0, 1, 2, 3, 4],
+        "width": w, "height": h, "sample_count": spp, "max_path_length": 1 if rad else 0, "timestamps": [ts0], "debug_words": [5, 6, 7] if rad else [0, 1, 2, 3, 4],
         "cam_src": f32(cam["cam_src"]), "cam_dir": f32(cam["cam_dir"]), "cam_up": f32(cam["cam_up"]),
         "cam_right": f32(cam["cam_right"]), "cam_left_bottom": f32(cam["cam_left_bottom"]),
         "vertexShader": open(os.path.join(REF, "vertexShader.glsl")).read(),
@@ -94,6 +104,11 @@ def run_prim_case(name):
     res = call_harness(name, payload)
     words = [np.frombuffer(base64.b64decode(b), dtype="<u4").reshape(h, w) for b in res["frames"]]
     os.makedirs(PRIM_OUT, exist_ok=True)
+    if rad:
+        np.savez_compressed(os.path.join(PRIM_OUT, name + ".npz"), rgb_bits=np.stack(words, axis=-1), scene=scene_name, width=w, height=h,
+                            sample_count=spp, max_path_length=1, timestamp=ts0, renderer=json.dumps(res["info"]))
+        print(name, res["info"], "mean", float(np.stack(words, axis=-1).view(np.float32).mean()), flush=True)
+        return
     np.savez_compressed(os.path.join(PRIM_OUT, name + ".npz"), tri=words[0].view(np.int32), t_bits=words[1], dir_bits=np.stack(words[2:5], axis=-1),
                         scene=scene_name, width=w, height=h, renderer=json.dumps(res["info"]))
     print(name, res["info"], "hits", int((words[0].view(np.int32) >= 0).sum()), "of", w * h, flush=True)
@@ -145,5 +160,5 @@ def run_case(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(PRIM_CASES)):
-        run_prim_case(n) if n in PRIM_CASES else run_case(n)
+    for n in (sys.argv[1:] or list(CASES) + list(PRIM_CASES) + list(RAD_CASES)):
+        run_prim_case(n) if (n in PRIM_CASES or n in RAD_CASES) else run_case(n)

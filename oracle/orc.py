@@ -176,13 +176,14 @@ def render_frames(s, p, timestamps, nthreads=0):
     return acc, total
 
 
-def blend_rgba8(p, cur_rgb, prev_rgba8, frame_number):
+def blend_rgba8(p, cur_rgb, prev_rgba8, frame_number, store=0):
+    """store: 0 = round(c * 255); 1 = SwiftShader's render-target store rule (see ptx_oracle.c to_unorm8)."""
     out = np.zeros((p.height, p.width, 4), dtype=np.uint8)
     cp = c_params(p)
     cur = np.ascontiguousarray(cur_rgb, dtype=np.float32)
     prev = None if prev_rgba8 is None else np.ascontiguousarray(prev_rgba8, dtype=np.uint8)
-    lib().orc_blend_rgba8(C.byref(cp), _fp(cur), None if prev is None else prev.ctypes.data_as(C.POINTER(C.c_uint8)),
-                          C.c_int32(frame_number), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    lib().orc_blend_rgba8_store(C.byref(cp), _fp(cur), None if prev is None else prev.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                C.c_int32(frame_number), C.c_int32(store), out.ctypes.data_as(C.POINTER(C.c_uint8)))
     return out
 
 

@@ -10,6 +10,7 @@
  *   cross(a,b) = (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y)
  *   normalize(v) = v * (1.0f / sqrt(dot(v,v)));  length(v) = sqrt(dot(v,v))
  *   min/max    = IEEE minNum/maxNum (the GLSL spec leaves NaN operands undefined)
+ *   float(uint) = two-step conversion of u32_to_f32 below (as SwiftShader does it)
  *   sin/cos    = the fixed polynomial of orc_sincos_2pi (GLSL leaves their precision open; the HIP
  *                kernels implement the same polynomial so build-vs-oracle is bit-exact)
  */
@@ -46,6 +47,16 @@ static inline float clamp01(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
 #define M_1_PI_F 0.3183098861837907f           /* glsl:3 */
 
 /* ------------------------------------------------------------------ RNG (glsl:302-313, 520) */
+/* vec2(uvec2): GLSL leaves the rounding of uint -> float open.  The contract follows the one implementation the
+ * reference shader can be run on here (SwiftShader; pinned by tests/golden/ref_prim/ *_rad_b1 fixtures): words
+ * below 2^31 are converted as signed integers (round to nearest even); words >= 2^31 as
+ * float(int(x - 2^31)) + 2^31f, i.e. with TWO roundings.  The result differs from the single correctly rounded
+ * conversion by one ulp for about 1 word in 16 of the upper half. */
+static inline float u32_to_f32(uint32_t x) {
+    float f = (float)(int32_t)(x & 0x7FFFFFFFu);
+    return (x >> 31) ? f + 2147483648.0f : f;
+}
+
 void orc_pcg2d(uint32_t s[2], float out[2]) {
     s[0] = 1664525u * s[0] + 1013904223u;
     s[1] = 1664525u * s[1] + 1013904223u;
@@ -57,8 +68,8 @@ void orc_pcg2d(uint32_t s[2], float out[2]) {
     s[1] += 1664525u * s[0];
     s[0] ^= s[0] >> 16;
     s[1] ^= s[1] >> 16;
-    out[0] = (float)s[0] * 2.32830643654e-10f;
-    out[1] = (float)s[1] * 2.32830643654e-10f;
+    out[0] = u32_to_f32(s[0]) * 2.32830643654e-10f;
+    out[1] = u32_to_f32(s[1]) * 2.32830643654e-10f;
 }
 
 void orc_seed_init(uint32_t px, uint32_t py, int32_t timestamp, uint32_t seed[2]) {
@@ -464,11 +475,25 @@ void orc_render_rows(const orc_scene *s, const orc_params *p, int32_t timestamp,
     if (c) acc_counters(c, &total);
 }
 
-/* unorm8 store of a render target: round(c * 255) */
-static inline uint8_t to_unorm8(float c) { return (uint8_t)floorf(clamp01(c) * 255.0f + 0.5f); }
+/* unorm8 store of a render target.  GL ES 3.0 2.1.6.1 allows either neighbour and prefers the nearest:
+ * store 0 = round(c * 255) (the preferred rule; what GPUs do);
+ * store 1 = the rule of the implementation the reference is run on here (SwiftShader; pinned byte for byte by
+ *           tests/golden/ref_frames/ *_b1): a 16-bit intermediate c16 = trunc(c * 65535), then (c16 - (c16 >> 8) + 128) >> 8. */
+static inline uint8_t to_unorm8(float c, int store) {
+    if (store == 1) {
+        uint32_t c16 = (uint32_t)(clamp01(c) * 65535.0f);
+        return (uint8_t)((c16 - (c16 >> 8) + 0x80u) >> 8);
+    }
+    return (uint8_t)floorf(clamp01(c) * 255.0f + 0.5f);
+}
 
 void orc_blend_rgba8(const orc_params *p, const float *cur_rgb, const uint8_t *prev_rgba8,
-                     int32_t frame_number, uint8_t *out_rgba8) { /* glsl:501-512,532-552 */
+                     int32_t frame_number, uint8_t *out_rgba8) {
+    orc_blend_rgba8_store(p, cur_rgb, prev_rgba8, frame_number, 0, out_rgba8);
+}
+
+void orc_blend_rgba8_store(const orc_params *p, const float *cur_rgb, const uint8_t *prev_rgba8,
+                           int32_t frame_number, int32_t store, uint8_t *out_rgba8) { /* glsl:501-512,532-552 */
     const uint32_t W = p->width, H = p->height;
     float aspect = (float)((double)W / (double)H);
     float bf = 1.0f / (float)(frame_number + 1);
@@ -483,6 +508,13 @@ void orc_blend_rgba8(const orc_params *p, const float *cur_rgb, const uint8_t *p
                 /* NEAREST + REPEAT (WebGL default wrap; modules/bufferManager.js:19-20 sets only filters) */
                 float fu = u - floorf(u), fv = v - floorf(v);
                 int32_t sx = (int32_t)floorf(fu * (float)W), sy = (int32_t)floorf(fv * (float)H);
+                if (store == 1) { /* SwiftShader's NEAREST addressing: 16-bit truncated coordinate, texel = (c16 * size) >> 16;
+                                     differs from the line above only where the coordinate sits on a texel boundary */
+                    uint32_t u16 = (uint32_t)(fu * 65536.0f), v16 = (uint32_t)(fv * 65536.0f);
+                    if (u16 > 65535u) u16 = 65535u;
+                    if (v16 > 65535u) v16 = 65535u;
+                    sx = (int32_t)(((uint64_t)u16 * W) >> 16); sy = (int32_t)(((uint64_t)v16 * H) >> 16);
+                }
                 if (sx >= (int32_t)W) sx = (int32_t)W - 1;
                 if (sy >= (int32_t)H) sy = (int32_t)H - 1;
                 const uint8_t *q = prev_rgba8 + 4 * ((size_t)sy * W + sx);
@@ -491,7 +523,7 @@ void orc_blend_rgba8(const orc_params *p, const float *cur_rgb, const uint8_t *p
             for (int k = 0; k < 3; k++) {
                 float cur = cur_rgb[3 * i + k];
                 float b = prev[k] * (1.0f - bf) + cur * bf; /* mix(x,y,a) = x*(1-a) + y*a */
-                out_rgba8[4 * i + k] = to_unorm8(b);
+                out_rgba8[4 * i + k] = to_unorm8(b, store);
             }
             out_rgba8[4 * i + 3] = 255;
         }

@@ -35,6 +35,13 @@ __device__ __forceinline__ bool any_ne(V3 a, V3 b) { return a.x != b.x || a.y !=
 #define PTX_M_PI 3.141592653589793238462643f   // glsl:2
 #define PTX_M_1_PI 0.3183098861837907f         // glsl:3
 
+// vec2(uvec2) of the contract: words >= 2^31 are converted as float(int(x - 2^31)) + 2^31f (two roundings), which is
+// what the reference shader does on SwiftShader (GLSL leaves the rounding open; oracle/ptx_oracle.c u32_to_f32).
+__device__ __forceinline__ float u32_to_f32(uint32_t x) {
+    float f = (float)(int32_t)(x & 0x7FFFFFFFu);
+    return (x >> 31) ? f + 2147483648.0f : f;
+}
+
 // glsl:302-313 (PCG2D).  Returns vec2(seed) * 2^-32.
 __device__ __forceinline__ void pcg2d(uint32_t& sx, uint32_t& sy, float& r0, float& r1) {
     sx = 1664525u * sx + 1013904223u;
@@ -47,8 +54,8 @@ __device__ __forceinline__ void pcg2d(uint32_t& sx, uint32_t& sy, float& r0, flo
     sy += 1664525u * sx;
     sx ^= sx >> 16;
     sy ^= sy >> 16;
-    r0 = (float)sx * 2.32830643654e-10f;
-    r1 = (float)sy * 2.32830643654e-10f;
+    r0 = u32_to_f32(sx) * 2.32830643654e-10f;
+    r1 = u32_to_f32(sy) * 2.32830643654e-10f;
 }
 
 // sincos contract: theta in [0, 2pi]; q = nearest multiple of pi/2; 3-constant Cody-Waite

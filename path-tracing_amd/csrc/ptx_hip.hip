@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void k_pack_rgba8(const float4* __restrict__ a
 // Reference-compatible progressive blend (option "compat_rgba8"): glsl:532-552 through the RGBA8 ping-pong render targets
 // of modules/bufferManager.js:18 -- out = unorm8(mix(prev, cur, 1 / (frameNumber + 1))), where prev is read back from
 // the 8-bit target with the shader's aspect-shifted texture coordinate (glsl:501-512; NEAREST, REPEAT wrap).
+// rules: what GL leaves to the implementation.  1 = the preferred ones (store round(c * 255); texel floor(coord * size));
+// 2 = SwiftShader's, the implementation the reference's committed frames come from (store through a truncated 16-bit
+// intermediate; texel (trunc(coord * 65536) * size) >> 16), under which those frames are reproduced byte for byte.
 __global__ __launch_bounds__(256) void k_blend_rgba8(const uchar4* __restrict__ prev, const float4* __restrict__ cur, uchar4* __restrict__ out,
-                                                     uint32_t W, uint32_t H, float aspect, float bf) {
+                                                     uint32_t W, uint32_t H, float aspect, float bf, int rules) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= W * H) return;
     const uint32_t x = p % W, y = p / W;
@@ -113,6 +116,10 @@ __global__ __launch_bounds__(256) void k_blend_rgba8(const uchar4* __restrict__ 
     else if (aspect < 1.0f) { v = v / aspect; v = v - 0.125f; }
     const float fu = u - floorf(u), fv = v - floorf(v);
     int sx = (int)floorf(fu * (float)W), sy = (int)floorf(fv * (float)H);
+    if (rules == 2) {
+        const uint32_t u16 = min((uint32_t)(fu * 65536.0f), 65535u), v16 = min((uint32_t)(fv * 65536.0f), 65535u);
+        sx = (int)(((uint64_t)u16 * W) >> 16); sy = (int)(((uint64_t)v16 * H) >> 16);
+    }
     if (sx >= (int)W) sx = (int)W - 1;
     if (sy >= (int)H) sy = (int)H - 1;
     const uchar4 q = prev[(size_t)sy * W + sx];
@@ -122,7 +129,12 @@ __global__ __launch_bounds__(256) void k_blend_rgba8(const uchar4* __restrict__ 
     unsigned char o[3];
     for (int k = 0; k < 3; k++) {
         const float b = pr[k] * (1.0f - bf) + cu[k] * bf;      // mix(x, y, a) = x * (1 - a) + y * a
-        o[k] = (unsigned char)floorf(clamp01(b) * 255.0f + 0.5f);
+        if (rules == 2) {
+            const uint32_t c16 = (uint32_t)(clamp01(b) * 65535.0f);
+            o[k] = (unsigned char)((c16 - (c16 >> 8) + 0x80u) >> 8);
+        } else {
+            o[k] = (unsigned char)floorf(clamp01(b) * 255.0f + 0.5f);
+        }
     }
     out[p] = make_uchar4(o[0], o[1], o[2], 255);
 }
@@ -634,7 +646,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;
     else if (k == "pool_chunk" && value >= 1 && value <= 65536) ctx->opt_pool_chunk = (int)value;
-    else if (k == "compat_rgba8" && (value == 0 || value == 1)) ctx->opt_compat = (int)value;
+    else if (k == "compat_rgba8" && value >= 0 && value <= 2) ctx->opt_compat = (int)value;
     else if (k == "frame_batch" && value >= 0 && value <= 4096) ctx->opt_frame_batch = (int)value;
     else if (k == "tasks_per_wave" && value >= 64 && value <= (1 << 20)) ctx->opt_tasks_per_wave = (int)value;
     else return fail(ctx, PTX_ERR_INVALID, "ptx_set_option: unknown key or bad value: " + k);
@@ -798,7 +810,7 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
             for (uint32_t f = 0; f < nf; f++) {
                 const float bf = 1.0f / (float)(first_frame_number + f0 + f + 1u);        // glsl:537: 1.0 / float(frameNumber + 1)
                 hipLaunchKernelGGL(k_blend_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur],
-                                   ctx->d_fb + (size_t)f * npix, ctx->d_compat[ctx->compat_cur ^ 1], ctx->P.W, ctx->P.H, ctx->P.aspect, bf);
+                                   ctx->d_fb + (size_t)f * npix, ctx->d_compat[ctx->compat_cur ^ 1], ctx->P.W, ctx->P.H, ctx->P.aspect, bf, ctx->opt_compat);
                 ctx->compat_cur ^= 1;
             }
             HIP_TRY(ctx, hipGetLastError());

@@ -1,10 +1,14 @@
 """The oracle pin: frames rendered by the REFERENCE shader itself (verbatim text, SwiftShader WebGL2; fixtures
 written by oracle/gen_ref_frames.py) against the CPU oracle, and -- on the GPU box -- against the HIP path.
 
-Bar: with maxPathLength = 1 everything except sin/cos is exercised (RNG chaining, traversal,
-Moeller-Trumbore, the <= 10-attempt light loop, both visibility rules, pdf, MIS weight, clamp, unorm8) and frames
-must be byte-identical up to a handful of +-1 code values; deeper paths depend on SwiftShader's approximate
-sin/cos (glsl:321-322), decorrelate, and are compared statistically: unbiased means and PSNR at equal spp.
+Bar: with maxPathLength = 1 everything except sin/cos is exercised (RNG chaining and its uint -> float
+conversion, traversal, Moeller-Trumbore, the <= 10-attempt light loop, both visibility rules, pdf, MIS weight, clamp,
+the 8-bit store, the progressive blend) and frames must be BYTE-IDENTICAL once the two things GL leaves to the
+implementation -- the float -> unorm8 store of the render target and the texel NEAREST picks on an exact texel boundary --
+follow SwiftShader's rules (oracle: blend store=1; library: option compat_rgba8 = 2).  Under the rules GL prefers
+(round to nearest, floor: store=0 / compat_rgba8 = 1, and ptx_read_rgba8) a handful of +-1 code values remain, and the
+boundary columns of wide progressive frames.  Deeper paths depend on SwiftShader's approximate sin/cos (glsl:321-322),
+decorrelate, and are compared statistically: unbiased means and PSNR at equal spp.
 north_star tolerance for images: PSNR >= 40 dB against the reference (pixar_room, 8 bounces).
 """
 import glob
@@ -22,19 +26,19 @@ def psnr(a, b):
     return np.inf if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
 
-def check(case, frames_rgba8, ref):
+def check(case, frames_rgba8, ref, swiftshader_rules=False):
     bounces = int(ref["max_path_length"])
     for f in range(ref["frames"].shape[0]):
         mine, want = frames_rgba8[f], ref["frames"][f]
         same = (mine == want).all(axis=2).mean()
         dmax = np.abs(mine.astype(np.int32) - want.astype(np.int32)).max()
         dmean = abs(mine[..., :3].mean() - want[..., :3].mean())
-        if "_prog_" in case:
-            # Running blend through the 8-bit targets: +-1 code value per frame from the sin/cos freedom, carried along.
-            # On wide images the shader reads the previous target at an aspect-shifted coordinate (glsl:501-512) that
-            # falls EXACTLY on a texel boundary in some columns (16:9: every 9th); which texel NEAREST picks there is
-            # implementation-defined (SwiftShader quantises coordinates to 16 bits and lands one texel lower in some
-            # of them), so those columns may differ by more.
+        if bounces == 1 and swiftshader_rules:
+            assert (mine == want).all(), (case, f, same, dmax)                                 # byte-identical
+        elif "_prog_" in case:
+            # preferred GL rules: +-1 code value per frame from the store rule, carried along by the blend; on wide images
+            # the previous target is read at an aspect-shifted coordinate (glsl:501-512) that falls EXACTLY on a texel
+            # boundary in some columns (16:9: every 9th), where SwiftShader's 16-bit coordinate lands one texel lower
             big = (np.abs(mine.astype(np.int32) - want.astype(np.int32)).max(axis=2) > 1)
             cols = np.unique(np.nonzero(big)[1])
             w = mine.shape[1]
@@ -64,29 +68,32 @@ def test_fixtures_present():
     assert {"my_cornell_6_b1", "cornell_c1", "pixar_room_b8", "pixar_room_b1"} <= set(CASES)
 
 
+@pytest.mark.parametrize("store", [0, 1])
 @pytest.mark.parametrize("case", CASES)
-def test_oracle_matches_reference_shader(ptx, orc, case):
+def test_oracle_matches_reference_shader(ptx, orc, case, store):
     ref, s, p = load(ptx, case)
     assert "SwiftShader" in str(ref["renderer"])
     if "_prog_" in case:      # the reference's running blend: frameNumber = f, previous 8-bit target fed back (glsl:532-552)
         frames, prev = [], None
         for f, ts in enumerate(ref["timestamps"]):
-            prev = orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], prev, f)
+            prev = orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], prev, f, store=store)
             frames.append(prev)
     else:
-        frames = [orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], None, 0) for ts in ref["timestamps"]]
-    check(case, frames, ref)
+        frames = [orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], None, 0, store=store) for ts in ref["timestamps"]]
+    check(case, frames, ref, swiftshader_rules=(store == 1))
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rules", [1, 2])
 @pytest.mark.parametrize("case", CASES)
-def test_gpu_matches_reference_shader(ptx, gpu_ctx, case):
+def test_gpu_matches_reference_shader(ptx, gpu_ctx, case, rules):
     ref, s, p = load(ptx, case)
     gpu_ctx.upload_scene(s)
     gpu_ctx.set_params(p)
     frames = []
-    if "_prog_" in case:      # option compat_rgba8: the library keeps the reference's two 8-bit targets itself
-        gpu_ctx.set_option("compat_rgba8", 1)
+    # option compat_rgba8: the library keeps the reference's two 8-bit targets itself (1 = preferred GL rules, 2 = SwiftShader's)
+    gpu_ctx.set_option("compat_rgba8", rules)
+    if "_prog_" in case:
         gpu_ctx.reset_accum()
         for f, ts in enumerate(ref["timestamps"]):
             gpu_ctx.render_frames([int(ts)], first_frame_number=f)
@@ -94,13 +101,15 @@ def test_gpu_matches_reference_shader(ptx, gpu_ctx, case):
         gpu_ctx.reset_accum()                                                  # the same frames in one call (one batch)
         gpu_ctx.render_frames([int(ts) for ts in ref["timestamps"]])
         assert (gpu_ctx.read_compat_rgba8() == frames[-1]).all()
-        gpu_ctx.set_option("compat_rgba8", 0)
     else:
         for ts in ref["timestamps"]:
             gpu_ctx.reset_accum()
             gpu_ctx.render_frames([int(ts)])
-            frames.append(gpu_ctx.read_rgba8(apply_gamma=False, flip_y=False))   # == the reference's RGBA8 target at frameNumber 0
-    check(case, frames, ref)
+            frames.append(gpu_ctx.read_compat_rgba8())                          # the reference's RGBA8 target at frameNumber 0
+            if rules == 1:
+                assert (gpu_ctx.read_rgba8(apply_gamma=False, flip_y=False) == frames[-1]).all()
+    gpu_ctx.set_option("compat_rgba8", 0)
+    check(case, frames, ref, swiftshader_rules=(rules == 2))
 
 
 # ---------------------------------------------------------------- primary-ray words from the derived debug shader (ref_prim/)
@@ -108,7 +117,7 @@ def test_gpu_matches_reference_shader(ptx, gpu_ctx, case):
 # traversal and intersection code (oracle/gen_ref_frames.py derive_debug_shader adds only the word dump).  Integer / bit
 # parity, so the bar is equality; pixels where SwiftShader itself disagrees would be listed as documented ties (none).
 PRIM = os.path.join(os.path.dirname(__file__), "golden", "ref_prim")
-PRIM_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(PRIM, "*.npz")))
+PRIM_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(PRIM, "*_prim.npz")))
 
 
 def load_prim(ptx, case):
@@ -149,4 +158,44 @@ def test_gpu_primary_words_match_reference_shader(ptx, gpu_ctx, case):
         gpu_ctx.set_option("pipeline", pipeline)
         t, tri = gpu_ctx.trace_closest(o, d)
         assert (tri.reshape(z["tri"].shape) == z["tri"]).all() and (t.view(np.uint32).reshape(z["tri"].shape) == z["t_bits"]).all(), pipeline
+    gpu_ctx.set_option("pipeline", 2)
+
+
+# ---------------------------------------------------------------- radiance bits at maxPathLength = 1 (ref_prim/*_rad_b1)
+# Float bits of clamp(mean radiance) (glsl:516-529) of one frame, dumped by the same derived shader.  With one bounce no
+# value depends on sin/cos, so the WHOLE shading arithmetic (RNG words and their float conversion, light sampling, both
+# visibility rules, solid angle, pdf, MIS weight, sample mean, clamp) is compared bit for bit: the bar is equality.
+RAD_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(PRIM, "*_rad_b1.npz")))
+
+
+def load_rad(ptx, case):
+    z = np.load(os.path.join(PRIM, case + ".npz"))
+    name = str(z["scene"])
+    return z, ptx.load_scene(name), ptx.config_params(name, int(z["width"]), int(z["height"]), int(z["sample_count"]), 1)
+
+
+def test_rad_fixtures_present():
+    assert {"my_cornell_6_rad_b1", "my_cornell_6_tall_rad_b1", "bedroom2_v5_rad_b1", "pixar_room_rad_b1"} <= set(RAD_CASES)
+
+
+@pytest.mark.parametrize("case", RAD_CASES)
+def test_oracle_radiance_bits_match_reference_shader(ptx, orc, case):
+    z, s, p = load_rad(ptx, case)
+    assert "SwiftShader" in str(z["renderer"])
+    rgb, _ = orc.render_frame(s, p, int(z["timestamp"]))
+    assert (rgb.view(np.uint32) == z["rgb_bits"]).all()
+    assert (z["rgb_bits"].view(np.float32) > 0).mean() > 0.2          # lit pixels, not a black frame
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", RAD_CASES)
+def test_gpu_radiance_bits_match_reference_shader(ptx, gpu_ctx, case):
+    z, s, p = load_rad(ptx, case)
+    gpu_ctx.upload_scene(s)
+    gpu_ctx.set_params(p)
+    for pipeline in (0, 1, 2):
+        gpu_ctx.set_option("pipeline", pipeline)
+        gpu_ctx.reset_accum()
+        gpu_ctx.render_frames([int(z["timestamp"])])
+        assert (gpu_ctx.read_sum().view(np.uint32) == z["rgb_bits"]).all(), pipeline   # one frame: the sum IS the frame
     gpu_ctx.set_option("pipeline", 2)
