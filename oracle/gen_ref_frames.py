@@ -114,6 +114,53 @@ def run_prim_case(name):
     print(name, res["info"], "hits", int((words[0].view(np.int32) >= 0).sum()), "of", w * h, flush=True)
 
 
+# Probes of what GLSL leaves to the implementation, evaluated by the same derived shader on the same GL implementation
+# (the tail of main() computes them from pixel indices and uniforms; nothing of the scene is used):
+#   sincos: float bits of theta = 2 pi i / 16384, sin(theta), cos(theta), sqrt(i / 16384) for i = 0 .. 16383
+#   minmax: min/max with NaN and infinite operands (NaN = 0 * (1 / 0) built from the uniform maxPathLength = 0)
+PROBE_CASES = {"sincos": 128, "minmax": 4}
+MINMAX_EXPR = ["min(qn, one)", "min(one, qn)", "max(qn, one)", "max(one, qn)", "min(ninf, qn)", "max(ninf, qn)", "min(qn, ninf)", "max(qn, ninf)",
+               "nan2", "min(nan2, one)", "min(one, nan2)", "max(nan2, one)", "max(one, nan2)", "pinf", "ninf", "(qn <= one) ? 1.0f : 0.0f"]
+
+
+def run_probe_case(name):
+    m = ptx_import.load()
+    w = h = PROBE_CASES[name]
+    s = m.load_scene("my_cornell_6")
+    cam = m.load_camera("my_cornell_6")
+    f32 = lambda v: [float(np.float32(x)) for x in v]  # noqa: E731
+    sh = derive_debug_shader(open(os.path.join(REF, "fragmentShaderPathTracing.glsl")).read())
+    a = sh.index("    uint w = debugWord == 0")
+    b = sh.index("\n", a)
+    if name == "sincos":
+        nwords = 4
+        probe = ("    uint idx = uint(gl_FragCoord.y) * %du + uint(gl_FragCoord.x);\n    float rr = float(idx) * %sf;\n    float th = 2.0f * M_PI * rr;\n"
+                 "    uint w = debugWord == 0 ? floatBitsToUint(th) : (debugWord == 1 ? floatBitsToUint(sin(th)) : (debugWord == 2 ? floatBitsToUint(cos(th)) : floatBitsToUint(sqrt(rr))));"
+                 % (w, repr(1.0 / (w * h))))
+    else:
+        nwords = len(MINMAX_EXPR)
+        probe = ("    float zz = float(maxPathLength); float pinf = 1.0f / zz; float ninf = -1.0f / zz; float nan2 = zz * pinf;\n"
+                 "    float qn = uintBitsToFloat(0x7fc00000u + uint(maxPathLength)); float one = float(sampleCount);\n"
+                 "    float dv[%d] = float[%d](%s);\n    uint w = floatBitsToUint(dv[debugWord]);" % (nwords, nwords, ", ".join(MINMAX_EXPR)))
+    payload = {
+        "width": w, "height": h, "sample_count": 1, "max_path_length": 0, "timestamps": [1000], "debug_words": list(range(nwords)),
+        "cam_src": f32(cam["cam_src"]), "cam_dir": f32(cam["cam_dir"]), "cam_up": f32(cam["cam_up"]),
+        "cam_right": f32(cam["cam_right"]), "cam_left_bottom": f32(cam["cam_left_bottom"]),
+        "vertexShader": open(os.path.join(REF, "vertexShader.glsl")).read(), "fragmentShader": sh[:a] + probe + sh[b:],
+        "scene": {"T": s.T, "N": s.N, "L": s.L, **{k: getattr(s, k).tolist() for k in
+                  ("coords", "normals", "colors", "emissions", "light_tri", "node_min", "node_max", "node_miss", "node_first", "node_count", "inorder_tri")}},
+    }
+    res = call_harness(name, payload)
+    words = np.stack([np.frombuffer(base64.b64decode(b_), dtype="<u4").reshape(-1) for b_ in res["frames"]])
+    os.makedirs(PRIM_OUT, exist_ok=True)
+    if name == "sincos":
+        np.savez_compressed(os.path.join(PRIM_OUT, "probe_sincos.npz"), theta_bits=words[0], sin_bits=words[1], cos_bits=words[2], sqrt_bits=words[3],
+                            renderer=json.dumps(res["info"]))
+    else:
+        np.savez_compressed(os.path.join(PRIM_OUT, "probe_minmax.npz"), expr=np.asarray(MINMAX_EXPR), bits=words[:, 0], renderer=json.dumps(res["info"]))
+    print(name, res["info"], [hex(int(x)) for x in words[:, 1 if name == "sincos" else 0]], flush=True)
+
+
 def kaleido_exe():
     import kaleido
     return os.path.join(os.path.dirname(kaleido.__file__), "executable", "kaleido")
@@ -160,5 +207,5 @@ def run_case(name):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or list(CASES) + list(PRIM_CASES) + list(RAD_CASES)):
-        run_prim_case(n) if (n in PRIM_CASES or n in RAD_CASES) else run_case(n)
+    for n in (sys.argv[1:] or list(CASES) + list(PRIM_CASES) + list(RAD_CASES) + list(PROBE_CASES)):
+        run_probe_case(n) if n in PROBE_CASES else (run_prim_case(n) if (n in PRIM_CASES or n in RAD_CASES) else run_case(n))

@@ -9,10 +9,10 @@
  *   dot(a,b)   = (a.x*b.x + a.y*b.y) + a.z*b.z
  *   cross(a,b) = (a.y*b.z - b.y*a.z, a.z*b.x - b.z*a.x, a.x*b.y - b.x*a.y)
  *   normalize(v) = v * (1.0f / sqrt(dot(v,v)));  length(v) = sqrt(dot(v,v))
- *   min/max    = IEEE minNum/maxNum (the GLSL spec leaves NaN operands undefined)
+ *   min(a,b)   = a < b ? a : b,  max(a,b) = a > b ? a : b  (a NaN operand yields b: SwiftShader's behaviour)
  *   float(uint) = two-step conversion of u32_to_f32 below (as SwiftShader does it)
- *   sin/cos    = the fixed polynomial of orc_sincos_2pi (GLSL leaves their precision open; the HIP
- *                kernels implement the same polynomial so build-vs-oracle is bit-exact)
+ *   sin/cos    = the operation sequence of orc_sincos_2pi (GLSL leaves their precision open; it is the one SwiftShader
+ *                evaluates, and the HIP kernels implement the same sequence so build-vs-oracle is bit-exact)
  */
 #include "ptx_oracle.h"
 #include <math.h>
@@ -38,9 +38,11 @@ static inline v3 cross(v3 a, v3 b) {
 }
 static inline float length3(v3 a) { return sqrtf(dot(a, a)); }
 static inline v3 normalize3(v3 a) { return scl(a, 1.0f / sqrtf(dot(a, a))); }
-/* IEEE minNum / maxNum: a NaN operand yields the other operand. */
-static inline float fmin_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
-static inline float fmax_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? b : a)); }
+/* min/max with a NaN operand (GLSL: undefined) return the SECOND operand, as on the implementation the reference is run
+ * on here (SwiftShader; probed with the derived debug shader: min(NaN,1) = 1, min(1,NaN) = NaN, max likewise).  This
+ * decides which boxes a ray lying exactly in a bounding plane (0 * inf = NaN slabs) enters: glsl:183-187. */
+static inline float fmin_(float a, float b) { return (a < b) ? a : b; }
+static inline float fmax_(float a, float b) { return (a > b) ? a : b; }
 static inline float clamp01(float x) { return fmin_(fmax_(x, 0.0f), 1.0f); }
 
 #define M_PI_F 3.141592653589793238462643f     /* glsl:2 */
@@ -79,27 +81,25 @@ void orc_seed_init(uint32_t px, uint32_t py, int32_t timestamp, uint32_t seed[2]
 }
 
 /* ------------------------------------------------------------------ sincos contract
- * theta in [0, 2*pi] (theta = f32(2*pi) * r, r in [0,1]).  q = nearest multiple of pi/2 (0..4),
- * three-constant Cody-Waite reduction (q*P1 exact), cephes single-precision minimax polynomials
- * on [-pi/4, pi/4], every operation a separately rounded binary32 op.  |error| <= ~1.2e-7. */
+ * GLSL leaves the precision of sin/cos open; the contract is the sequence of separately rounded binary32 operations that
+ * the implementation the reference is run on here (SwiftShader) evaluates, found by comparing float bits of 16384 angles
+ * over [0, 2*pi] dumped by the derived debug shader (oracle/gen_ref_frames.py; fixture tests/golden/ref_prim/sincos.npz):
+ * y = x / (2 pi) - round(..) in [-1/2, 1/2]; degree-7 sine and degree-6 cosine of the QUARTER angle pi*y/2; two angle
+ * doublings, the second normalised by 1 / (s2^2 + c2^2); cos(x) = sin(x + pi/2).  |error| <= 7e-7. */
+static inline float ss_sin(float x) {
+    float y = x * 1.59154943e-1f;
+    y = y - rintf(y);                                  /* round to nearest even */
+    float y2 = y * y;
+    float c1 = y2 * (y2 * (y2 * -0.0204391631f + 0.2536086171f) + -1.2336977925f) + 1.0f;
+    float s1 = y * (y2 * (y2 * (y2 * -0.0046075748f + 0.0796819754f) + -0.645963615f) + 1.5707963235f);
+    float c2 = c1 * c1 - s1 * s1;
+    float s2 = (2.0f * s1) * c1;
+    return ((2.0f * s2) * c2) * (1.0f / (s2 * s2 + c2 * c2));
+}
+
 void orc_sincos_2pi(float theta, float *so, float *co) {
-    const float TWO_OVER_PI = 0.636619772367581343f;
-    const float P1 = 1.5703125f, P2 = 4.837512969970703125e-4f, P3 = 7.54978995489188216e-8f;
-    int q = (int)(theta * TWO_OVER_PI + 0.5f);
-    float fq = (float)q;
-    float y = ((theta - fq * P1) - fq * P2) - fq * P3;
-    float z = y * y;
-    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * y + y;
-    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
-               - 0.5f * z + 1.0f;
-    float s, c;
-    switch (q & 3) {
-        case 0: s = sp; c = cp; break;
-        case 1: s = cp; c = -sp; break;
-        case 2: s = -sp; c = -cp; break;
-        default: s = -cp; c = sp; break;
-    }
-    *so = s; *co = c;
+    *so = ss_sin(theta);
+    *co = ss_sin(theta + 1.57079632f);
 }
 
 /* ------------------------------------------------------------------ intersections */

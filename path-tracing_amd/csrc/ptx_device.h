@@ -58,22 +58,24 @@ __device__ __forceinline__ void pcg2d(uint32_t& sx, uint32_t& sy, float& r0, flo
     r1 = u32_to_f32(sy) * 2.32830643654e-10f;
 }
 
-// sincos contract: theta in [0, 2pi]; q = nearest multiple of pi/2; 3-constant Cody-Waite
-// reduction; cephes single-precision polynomials on [-pi/4, pi/4]; every op separately rounded.
+__device__ __forceinline__ float rcp_det(float a);
+
+// sincos contract (oracle/ptx_oracle.c ss_sin): the operation sequence SwiftShader evaluates for sin(x) --
+// y = x / (2 pi) reduced to [-1/2, 1/2], sine / cosine polynomials of the quarter angle, two angle doublings, the second
+// normalised by a correctly rounded 1 / (s2^2 + c2^2) -- and cos(x) = sin(x + pi/2); every op separately rounded.
+__device__ __forceinline__ float ss_sin(float x) {
+    float y = x * 1.59154943e-1f;
+    y = y - __builtin_rintf(y);
+    const float y2 = y * y;
+    const float c1 = y2 * (y2 * (y2 * -0.0204391631f + 0.2536086171f) + -1.2336977925f) + 1.0f;
+    const float s1 = y * (y2 * (y2 * (y2 * -0.0046075748f + 0.0796819754f) + -0.645963615f) + 1.5707963235f);
+    const float c2 = c1 * c1 - s1 * s1;
+    const float s2 = (2.0f * s1) * c1;
+    return ((2.0f * s2) * c2) * rcp_det(s2 * s2 + c2 * c2);      // the denominator is 1 +- 1e-6: rcp_det == 1.0f / den
+}
 __device__ __forceinline__ void sincos_2pi(float theta, float& s, float& c) {
-    const float TWO_OVER_PI = 0.636619772367581343f;
-    const float P1 = 1.5703125f, P2 = 4.837512969970703125e-4f, P3 = 7.54978995489188216e-8f;
-    int q = (int)(theta * TWO_OVER_PI + 0.5f);
-    float fq = (float)q;
-    float y = ((theta - fq * P1) - fq * P2) - fq * P3;
-    float z = y * y;
-    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * y + y;
-    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
-    int k = q & 3;
-    float a = (k & 1) ? cp : sp;
-    float b = (k & 1) ? sp : cp;
-    s = (k & 2) ? -a : a;
-    c = (k == 1 || k == 2) ? -b : b;
+    s = ss_sin(theta);
+    c = ss_sin(theta + 1.57079632f);
 }
 
 // glsl:315-337
@@ -115,6 +117,25 @@ __device__ __forceinline__ bool slab_node(V3 o, V3 inv, float4 a, float4 b, floa
     float tf = fminf(fminf(fmaxf(lo.x, hi.x), fmaxf(lo.y, hi.y)), fmaxf(zz.x, zz.y));
     tNear = tn;
     return (tn <= tf) && (tf > 0.0f);
+}
+
+// glsl:175-191 for a ray whose 1/d has an infinite (or NaN) component, on a record of the REFERENCE tree.  When such a ray
+// also starts exactly in a bounding plane, 0 * inf = NaN reaches min/max, whose result GLSL leaves undefined; the contract
+// follows SwiftShader, where min(a, b) = a < b ? a : b and max(a, b) = a > b ? a : b (a NaN operand yields b; probed with
+// the derived debug shader).  A NaN in the y slab then hides the x and y slabs, one in the z slab rejects the box: the
+// result depends on the reference's own hierarchy, so these rays walk the reference tree (DScene::ref_base), unpruned.
+__device__ __forceinline__ float min_2nd(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float max_2nd(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ bool slab_node_ref(V3 o, V3 inv, float4 a, float4 b, float& tNear) {
+    const float t1x = (a.x - o.x) * inv.x, t1y = (a.y - o.y) * inv.y, t1z = (b.x - o.z) * inv.z;
+    const float t2x = (a.z - o.x) * inv.x, t2y = (a.w - o.y) * inv.y, t2z = (b.y - o.z) * inv.z;
+    const float tn = max_2nd(max_2nd(min_2nd(t1x, t2x), min_2nd(t1y, t2y)), min_2nd(t1z, t2z));
+    const float tf = min_2nd(min_2nd(max_2nd(t1x, t2x), max_2nd(t1y, t2y)), max_2nd(t1z, t2z));
+    tNear = tn;
+    return (tn <= tf) && (tf > 0.0f);
+}
+__device__ __forceinline__ bool inv_degenerate(V3 inv) {      // |x| < inf is false for inf and NaN
+    return !(fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff());
 }
 
 // The slab test on a record whose planes are stored entry-first for the ray's direction octant (leaf-SAH layouts):

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <limits>
 
 using namespace ptx;
 
@@ -163,7 +164,7 @@ struct ptx_ctx {
     // scene
     bool have_scene = false;
     DScene S = {};
-    const float4* nodes_sah = nullptr;   // leaf-SAH tree over the reference leaves: 8 direction-octant layouts, or nullptr
+    const float4* nodes_sah = nullptr;   // leaf-SAH tree over the reference leaves: 8 direction-octant layouts + the reference tree, or nullptr
     int N_sah = 0;
     std::vector<void*> scene_allocs;
 
@@ -204,7 +205,7 @@ static std::string g_create_error;
 static inline bool opt_prune(const ptx_ctx* c) { return (c->opt_traversal & 1) != 0; }
 static inline DScene scene_view(const ptx_ctx* c) {
     DScene S = c->S;
-    if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; S.oct_stride = (uint32_t)c->N_sah * 32u; }
+    if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; S.oct_stride = (uint32_t)c->N_sah * 32u; S.ref_base = 8u * S.oct_stride; }
     return S;
 }
 
@@ -571,6 +572,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     }
     DScene S = {};
     int rc;
+    const std::vector<float4> ref_nodes = nodes;      // {min.xyz, miss}, {max.xyz, fc}: becomes layout 8 behind the octant layouts
     repack_nodes(nodes);
     if ((rc = upload(ctx, nodes, &S.nodes)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, aN, &S.attrN)) ||
         (rc = upload(ctx, aC, &S.attrC)) || (rc = upload(ctx, aE, &S.attrE)) || (rc = upload(ctx, light, &S.light))) {
@@ -583,9 +585,24 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         std::vector<float4> sah;
         int n2 = 0;
         if (build_leaf_sah(sc, sah, &n2)) {
-            repack_nodes(sah);
-            if ((rc = upload(ctx, sah, &ctx->nodes_sah))) { free_scene(ctx); return rc; }
-            ctx->N_sah = n2;
+            // nine layouts of nmax records each: the eight octant layouts of the leaf-SAH tree, then the reference tree
+            // itself, which rays with an infinite 1/d component walk (slab_node_ref).  Shorter layouts end in records that
+            // no ray enters (NaN box, miss link -1, nothing to queue), so one node count serves all nine.
+            const size_t nmax = std::max((size_t)n2, (size_t)N);
+            if ((uint64_t)nmax * 32u * 9u < (1ull << 32)) {
+                const float nan = std::numeric_limits<float>::quiet_NaN();    // NaN bounds: a miss under every slab test here
+                std::vector<float4> all(nmax * 2 * 9);
+                for (size_t q = 0; q < nmax * 9; q++) {
+                    all[2 * q] = make_float4(nan, nan, nan, bits(-1));
+                    all[2 * q + 1] = make_float4(nan, nan, nan, bits(-2));
+                }
+                for (int oct = 0; oct < 8; oct++)
+                    std::copy(sah.begin() + (size_t)oct * n2 * 2, sah.begin() + (size_t)(oct + 1) * n2 * 2, all.begin() + (size_t)oct * nmax * 2);
+                std::copy(ref_nodes.begin(), ref_nodes.end(), all.begin() + (size_t)8 * nmax * 2);
+                repack_nodes(all);
+                if ((rc = upload(ctx, all, &ctx->nodes_sah))) { free_scene(ctx); return rc; }
+                ctx->N_sah = (int)nmax;
+            }
         }
     }
     ctx->S = S;

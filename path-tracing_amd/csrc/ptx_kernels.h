@@ -28,6 +28,8 @@ struct DScene {
     const float4* light;   // 6 float4 per light
     int N, T, L;
     uint32_t oct_stride;   // bytes between the 8 direction-octant layouts of `nodes` (0: a single layout)
+    uint32_t ref_base;     // byte offset in `nodes` of the reference tree itself (layout 8 behind the octant layouts; 0 when
+                           // `nodes` IS the reference tree): rays with an infinite 1/d component walk it (slab_node_ref)
 };
 
 struct DParams {
@@ -121,7 +123,8 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
     uint32_t i = 0;                       // -1 (end) wraps to 0xFFFFFFFF >= N
     const uint32_t N = (uint32_t)S.N;
     float limit = 3.0e38f;
-    const uint32_t nbase = octant(d) * S.oct_stride;
+    const bool deg = inv_degenerate(inv);
+    const uint32_t nbase = deg ? S.ref_base : octant(d) * S.oct_stride;
     do {
         int pend[PTX_LEAF_BATCH];
         int n = 0;
@@ -132,8 +135,8 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
             const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
             if (COUNT) c.node_visits++;
             float tn;
-            bool hit = slab_node(o, inv, a, b, tn);
-            if (PRUNE) hit = hit && !(tn > limit);
+            bool hit = deg ? slab_node_ref(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn);
+            if (PRUNE) hit = hit && (deg || !(tn > limit));
             if (hit) {
                 const int fc = __float_as_int(b.w);
                 if (fc != -2) {
@@ -191,19 +194,20 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
 template <bool PRUNE, bool COUNT>
 __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, float& out_t, int& out_tri, LocalCnt& c) {
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const bool ordered = S.oct_stride != 0u && fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff();
+    const bool deg = inv_degenerate(inv);
+    const bool ordered = S.oct_stride != 0u && !deg;
     float best = 1.0e38f, limit = 3.0e38f;
     uint32_t best_k = 0xFFFFFFFFu;
     uint32_t i = 0;
     const uint32_t N = (uint32_t)S.N;
-    const uint32_t nbase = octant(d) * S.oct_stride;
+    const uint32_t nbase = deg ? S.ref_base : octant(d) * S.oct_stride;
     while (i < N) {
         const float4 a = ld16(S.nodes, nbase + (i << 5));
         const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
         if (COUNT) c.node_visits++;
         float tn;
-        bool hit = ordered ? slab_node_ordered(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn);
-        if (PRUNE) hit = hit && !(tn > limit);
+        bool hit = ordered ? slab_node_ordered(o, inv, a, b, tn) : (deg ? slab_node_ref(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn));
+        if (PRUNE) hit = hit && (deg || !(tn > limit));
         if (!hit) { i = (uint32_t)__float_as_int(b.z); continue; }
         i++;
         const int fc = __float_as_int(b.w);

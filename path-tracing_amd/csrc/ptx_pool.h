@@ -117,8 +117,14 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                         int miss = __float_as_int(b.z), fc = __float_as_int(b.w);
                         asm volatile("" : "+v"(miss), "+v"(fc));     // keep the links in the record's two loads (no third, dependent one)
                         if (COUNT) cnt_nodes++;
-                        bool hit = decltype(ORDERED)::value ? slab_node_ordered(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
-                        if (PRUNE) hit = hit && !(tn > limit);
+                        bool hit;
+                        if (!decltype(ORDERED)::value && (flags & F_INF)) {   // reference tree, SwiftShader's NaN rule, unpruned
+                            hit = slab_node_ref(ro, inv, a, b, tn);
+                            tn = 0.f;
+                        } else {
+                            hit = decltype(ORDERED)::value ? slab_node_ordered(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
+                            if (PRUNE) hit = hit && !(tn > limit);
+                        }
                         push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
                         item = (uint32_t)fc;
                         i = hit ? i + 1u : (uint32_t)miss;
@@ -273,14 +279,15 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                nbase = octant(rd) * S.oct_stride;
                 keys[lane] = PTX_POOL_KEY_NONE;
                 limit = 3.0e38f;
                 i = 0;
                 lastpos = head;
                 flags |= F_TRAV;
-                // |x| < inf is false for inf and NaN: such rays keep the selecting slab test
-                flags = (fabsf(inv.x) < __builtin_inff() && fabsf(inv.y) < __builtin_inff() && fabsf(inv.z) < __builtin_inff()) ? (flags & ~F_INF) : (flags | F_INF);
+                // rays with an infinite or NaN 1/d component walk the reference tree with the selecting slab test (slab_node_ref)
+                const bool deg = inv_degenerate(inv);
+                flags = deg ? (flags | F_INF) : (flags & ~F_INF);
+                nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
             }
             w_traced += (uint32_t)__popcll(__ballot(start_trav));
         }

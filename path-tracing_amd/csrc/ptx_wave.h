@@ -168,8 +168,9 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                     const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
                     if (COUNT) cnt_nodes++;
                     float tn;
-                    bool hit = slab_node(ro, inv, a, b, tn);
-                    if (PRUNE) hit = hit && !(tn > limit);
+                    const bool deg = (flags & F_INF) != 0;       // reference tree, SwiftShader's NaN rule, unpruned
+                    bool hit = deg ? slab_node_ref(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
+                    if (PRUNE) hit = hit && (deg || !(tn > limit));
                     const int fc = __float_as_int(b.w);
                     const bool push = hit && fc != -2;
 #pragma unroll
@@ -288,7 +289,9 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-                nbase = octant(rd) * S.oct_stride;
+                const bool deg = inv_degenerate(inv);
+                flags = deg ? (flags | F_INF) : (flags & ~F_INF);
+                nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
                 best = 1.0e38f; limit = 3.0e38f; best_tri = -1; best_k = 0xFFFFFFFFu;
                 i = 0; nq = 0; k = 0; kend = 0;
                 flags |= F_TRAV;

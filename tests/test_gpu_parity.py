@@ -289,6 +289,39 @@ def test_axis_aligned_rays(gpu_ctx, ptx, orc, pipeline):
             assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (traversal, memo)
 
 
+def test_rays_inside_bounding_planes(gpu_ctx, ptx, orc):
+    """Rays that start ON a bounding plane of some node and run inside it (e.g. a ceiling point towards the ceiling light of
+    my_cornell_6: y = 4, d.y = 0): 0 * inf = NaN slabs, decided by the second-operand rule of min/max and therefore by the
+    reference's own hierarchy -- every traversal mode must send them through the reference tree (slab_node_ref) and agree
+    with the oracle."""
+    for name in ("my_cornell_6", "cornell", "teapot"):
+        s = ptx.load_scene(name)
+        gpu_ctx.upload_scene(s)
+        rng = np.random.default_rng(11)
+        n = 6000
+        nmin, nmax = s.node_min.reshape(-1, 3), s.node_max.reshape(-1, 3)
+        o = (nmin[0] + (nmax[0] - nmin[0]) * rng.random((n, 3))).astype(np.float32)
+        d = rng.normal(size=(n, 3))
+        axis = rng.integers(0, 3, n)
+        node = rng.integers(0, s.N, n)
+        plane = np.where(rng.random(n) < 0.5, nmin[node, axis], nmax[node, axis])
+        o[np.arange(n), axis] = plane
+        d[np.arange(n), axis] = 0.0
+        d[np.arange(n // 6), (axis[: n // 6] + 1) % 3] = 0.0              # two zero components
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        if name == "my_cornell_6":
+            o[-1000:, 1] = 4.0; d[-1000:, 1] = 0.0                        # the ceiling plane itself
+            d[-1000:] = (d[-1000:] / np.linalg.norm(d[-1000:], axis=1, keepdims=True)).astype(np.float32)
+        wt, wtri, _ = orc.trace_closest(s, o, d)
+        assert (wtri >= 0).mean() > 0.05
+        for pipeline in (0, 2):
+            for traversal in (0, 1, 2, 3):
+                gpu_ctx.set_option("pipeline", pipeline); gpu_ctx.set_option("traversal", traversal)
+                t, tri = gpu_ctx.trace_closest(o, d)
+                assert (tri == wtri).all() and (bits(t) == bits(wt)).all(), (name, pipeline, traversal, int((tri != wtri).sum()))
+    gpu_ctx.set_option("pipeline", 2); gpu_ctx.set_option("traversal", 3)
+
+
 def test_accumulation_semantics(gpu_ctx, ptx, orc):
     s, p = setup(gpu_ctx, ptx, "my_cornell_6", 40, 24, spp=2, bounces=3)
     ts = ptx.scene.timestamps(7)

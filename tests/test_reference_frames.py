@@ -1,15 +1,14 @@
 """The oracle pin: frames rendered by the REFERENCE shader itself (verbatim text, SwiftShader WebGL2; fixtures
 written by oracle/gen_ref_frames.py) against the CPU oracle, and -- on the GPU box -- against the HIP path.
 
-Bar: with maxPathLength = 1 everything except sin/cos is exercised (RNG chaining and its uint -> float
-conversion, traversal, Moeller-Trumbore, the <= 10-attempt light loop, both visibility rules, pdf, MIS weight, clamp,
-the 8-bit store, the progressive blend) and frames must be BYTE-IDENTICAL once the two things GL leaves to the
-implementation -- the float -> unorm8 store of the render target and the texel NEAREST picks on an exact texel boundary --
-follow SwiftShader's rules (oracle: blend store=1; library: option compat_rgba8 = 2).  Under the rules GL prefers
-(round to nearest, floor: store=0 / compat_rgba8 = 1, and ptx_read_rgba8) a handful of +-1 code values remain, and the
-boundary columns of wide progressive frames.  Deeper paths depend on SwiftShader's approximate sin/cos (glsl:321-322),
-decorrelate, and are compared statistically: unbiased means and PSNR at equal spp.
-north_star tolerance for images: PSNR >= 40 dB against the reference (pixar_room, 8 bounces).
+Bar: BYTE-IDENTICAL frames, every scene, every path length (1, 3, 4 and 8 bounces), single frames and the progressive
+blend, once the two things GL leaves to the implementation outside the shader -- the float -> unorm8 store of the render
+target and the texel NEAREST picks on an exact texel boundary -- follow SwiftShader's rules (oracle: blend store=1;
+library: option compat_rgba8 = 2).  Inside the shader the contract already follows that implementation wherever GLSL
+leaves room: uint -> float conversion, sin/cos, min/max of NaN (DESIGN.md "Arithmetic contract"; ref_prim/probe_*.npz).
+Under the rules GL prefers for the store (round to nearest, floor: store=0 / compat_rgba8 = 1, and ptx_read_rgba8) a
+handful of +-1 code values remain, and the boundary columns of wide progressive frames.
+north_star tolerance for images: PSNR >= 40 dB against the reference (pixar_room, 8 bounces): met with infinite PSNR.
 """
 import glob
 import os
@@ -32,8 +31,7 @@ def check(case, frames_rgba8, ref, swiftshader_rules=False):
         mine, want = frames_rgba8[f], ref["frames"][f]
         same = (mine == want).all(axis=2).mean()
         dmax = np.abs(mine.astype(np.int32) - want.astype(np.int32)).max()
-        dmean = abs(mine[..., :3].mean() - want[..., :3].mean())
-        if bounces == 1 and swiftshader_rules:
+        if swiftshader_rules:
             assert (mine == want).all(), (case, f, same, dmax)                                 # byte-identical
         elif "_prog_" in case:
             # preferred GL rules: +-1 code value per frame from the store rule, carried along by the blend; on wide images
@@ -45,15 +43,10 @@ def check(case, frames_rgba8, ref, swiftshader_rules=False):
             aspect = np.float32(w / mine.shape[0])
             on_boundary = [abs(((x + 0.5) / w * aspect - 0.125) * w - round(((x + 0.5) / w * aspect - 0.125) * w)) < 1e-3 for x in cols]
             assert same >= 0.96 and all(on_boundary) and (aspect > 1 or not big.any()), (case, f, same, cols)
-        elif bounces == 1:
-            assert same >= 0.995 and dmax <= 1, (case, f, same, dmax)
         else:
-            assert dmean <= 0.01 * max(1.0, want[..., :3].mean()) + 0.3, (case, f, dmean)      # unbiased
-            assert same >= 0.65, (case, f, same)                                               # most low-spp pixels still equal
+            assert same >= 0.99 and dmax <= 1, (case, f, same, dmax, bounces)                  # store rule only: +-1 code value
         if case == "pixar_room_b8":
             assert psnr(mine, want) >= 40.0, psnr(mine, want)                                  # north_star tolerance
-        if case == "cornell_c1":
-            assert psnr(mine, want) >= 55.0 and same >= 0.99
 
 
 def load(ptx, case):
