@@ -200,7 +200,7 @@ class Context:
         return out
 
     def read_compat_rgba8(self, apply_gamma=False, flip_y=False):
-        """The reference's RGBA8 ping-pong target (option compat_rgba8 = 1)."""
+        """The reference's RGBA8 ping-pong target (option compat_rgba8 = 1 or 2, see include/ptx.h)."""
         out = self._img(4, np.uint8)
         self._check(self._lib.ptx_read_compat_rgba8(self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), int(apply_gamma), int(flip_y)))
         return out

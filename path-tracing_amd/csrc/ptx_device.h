@@ -123,14 +123,17 @@ __device__ __forceinline__ bool slab_node(V3 o, V3 inv, float4 a, float4 b, floa
 // also starts exactly in a bounding plane, 0 * inf = NaN reaches min/max, whose result GLSL leaves undefined; the contract
 // follows SwiftShader, where min(a, b) = a < b ? a : b and max(a, b) = a > b ? a : b (a NaN operand yields b; probed with
 // the derived debug shader).  A NaN in the y slab then hides the x and y slabs, one in the z slab rejects the box: the
-// result depends on the reference's own hierarchy, so these rays walk the reference tree (DScene::ref_base), unpruned.
+// result depends on the reference's own hierarchy, so these rays walk the reference tree (DScene::ref_base).  tNear is NaN
+// (then the box is a miss) or the entry distance of the slabs that were not hidden: a lower bound, so best-t pruning stays valid.
 __device__ __forceinline__ float min_2nd(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float max_2nd(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ bool slab_node_ref(V3 o, V3 inv, float4 a, float4 b, float& tNear) {
-    const float t1x = (a.x - o.x) * inv.x, t1y = (a.y - o.y) * inv.y, t1z = (b.x - o.z) * inv.z;
-    const float t2x = (a.z - o.x) * inv.x, t2y = (a.w - o.y) * inv.y, t2z = (b.y - o.z) * inv.z;
-    const float tn = max_2nd(max_2nd(min_2nd(t1x, t2x), min_2nd(t1y, t2y)), min_2nd(t1z, t2z));
-    const float tf = min_2nd(min_2nd(max_2nd(t1x, t2x), max_2nd(t1y, t2y)), max_2nd(t1z, t2z));
+    const f2 oxy = {o.x, o.y}, ixy = {inv.x, inv.y}, ozz = {o.z, o.z}, izz = {inv.z, inv.z};
+    const f2 lo = (f2{a.x, a.y} - oxy) * ixy;     // t1.xy   (the same packed products as slab_node)
+    const f2 hi = (f2{a.z, a.w} - oxy) * ixy;     // t2.xy
+    const f2 zz = (f2{b.x, b.y} - ozz) * izz;     // t1.z, t2.z
+    const float tn = max_2nd(max_2nd(min_2nd(lo.x, hi.x), min_2nd(lo.y, hi.y)), min_2nd(zz.x, zz.y));
+    const float tf = min_2nd(min_2nd(max_2nd(lo.x, hi.x), max_2nd(lo.y, hi.y)), max_2nd(zz.x, zz.y));
     tNear = tn;
     return (tn <= tf) && (tf > 0.0f);
 }

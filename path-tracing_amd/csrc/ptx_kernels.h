@@ -136,7 +136,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
             if (COUNT) c.node_visits++;
             float tn;
             bool hit = deg ? slab_node_ref(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn);
-            if (PRUNE) hit = hit && (deg || !(tn > limit));
+            if (PRUNE) hit = hit && !(tn > limit);
             if (hit) {
                 const int fc = __float_as_int(b.w);
                 if (fc != -2) {
@@ -207,7 +207,7 @@ __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, f
         if (COUNT) c.node_visits++;
         float tn;
         bool hit = ordered ? slab_node_ordered(o, inv, a, b, tn) : (deg ? slab_node_ref(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn));
-        if (PRUNE) hit = hit && (deg || !(tn > limit));
+        if (PRUNE) hit = hit && !(tn > limit);
         if (!hit) { i = (uint32_t)__float_as_int(b.z); continue; }
         i++;
         const int fc = __float_as_int(b.w);

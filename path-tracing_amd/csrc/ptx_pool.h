@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             if (PRUNE) limit = __uint_as_float((uint32_t)(keys[lane] >> 32)) * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
             const bool ordered = S.oct_stride != 0u && __ballot(walking && (flags & F_INF)) == 0ull;
-            auto walk = [&](auto ORDERED) {
+            auto walk = [&](auto MODE) {
 #pragma nounroll
                 for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
                     if (tail - head > (uint32_t)(PTX_POOL_QCAP - 64)) break;
@@ -117,14 +117,16 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                         int miss = __float_as_int(b.z), fc = __float_as_int(b.w);
                         asm volatile("" : "+v"(miss), "+v"(fc));     // keep the links in the record's two loads (no third, dependent one)
                         if (COUNT) cnt_nodes++;
-                        bool hit;
-                        if (!decltype(ORDERED)::value && (flags & F_INF)) {   // reference tree, SwiftShader's NaN rule, unpruned
-                            hit = slab_node_ref(ro, inv, a, b, tn);
-                            tn = 0.f;
-                        } else {
-                            hit = decltype(ORDERED)::value ? slab_node_ordered(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
-                            if (PRUNE) hit = hit && !(tn > limit);
-                        }
+                        // MODE 0: every walking lane takes the entry-first shortcut; 1: lanes with an infinite 1/d component walk
+                        // the reference tree with the selecting test (second-operand NaN rule), the others stay entry-first;
+                        // 2: single-layout views (the reference tree for everyone): selecting tests only
+                        // (on finite slabs the selecting test with either NaN rule IS the entry-first test, so in mode 1 one
+                        // instruction stream serves both kinds of lane instead of two divergent ones)
+                        const bool hit0 = decltype(MODE)::value == 0 ? slab_node_ordered(ro, inv, a, b, tn)
+                                        : (decltype(MODE)::value == 1 ? slab_node_ref(ro, inv, a, b, tn)
+                                        : ((flags & F_INF) ? slab_node_ref(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn)));
+                        bool hit = hit0;
+                        if (PRUNE) hit = hit && !(tn > limit);       // a NaN or partial tn is still a lower bound of the entry distance
                         push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
                         item = (uint32_t)fc;
                         i = hit ? i + 1u : (uint32_t)miss;
@@ -140,7 +142,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     if (__popcll(__ballot(trav && i < N)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
                 }
             };
-            if (ordered) walk(std::true_type{}); else walk(std::false_type{});
+            if (ordered) walk(std::integral_constant<int, 0>{});
+            else if (S.oct_stride != 0u) walk(std::integral_constant<int, 1>{});
+            else walk(std::integral_constant<int, 2>{});
         } else if (phase == 1) {
             const uint32_t n = min(len, 64u);
             const bool has = lane < n;

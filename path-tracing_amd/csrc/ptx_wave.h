@@ -168,9 +168,9 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                     const float4 b = ld16(S.nodes, nbase + (i << 5) + 16);
                     if (COUNT) cnt_nodes++;
                     float tn;
-                    const bool deg = (flags & F_INF) != 0;       // reference tree, SwiftShader's NaN rule, unpruned
+                    const bool deg = (flags & F_INF) != 0;       // reference tree, SwiftShader's NaN rule
                     bool hit = deg ? slab_node_ref(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
-                    if (PRUNE) hit = hit && (deg || !(tn > limit));
+                    if (PRUNE) hit = hit && !(tn > limit);
                     const int fc = __float_as_int(b.w);
                     const bool push = hit && fc != -2;
 #pragma unroll

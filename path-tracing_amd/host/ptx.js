@@ -45,7 +45,8 @@ class PathTracer {
   readLinear() { return this.addon.readLinear(this.handle, this.width, this.height); }
   readSum() { return this.addon.readSum(this.handle, this.width, this.height); }
   readRgba8(gamma, flipY) { return this.addon.readRgba8(this.handle, this.width, this.height, gamma !== false, flipY !== false); }
-  /** The reference's RGBA8 ping-pong target (setOption('compat_rgba8', 1) before rendering): what gl.readPixels returns in the browser. */
+  /** The reference's RGBA8 ping-pong target (setOption('compat_rgba8', 1 | 2) before rendering): what gl.readPixels returns in the browser
+   *  (1 = GL's preferred store / NEAREST rules, 2 = SwiftShader's; include/ptx.h). */
   readCompatRgba8(gamma, flipY) { return this.addon.readCompatRgba8(this.handle, this.width, this.height, gamma === true, flipY === true); }
   /** Checkpoint restore: accumulation := sum (Float32Array W*H*3 from readSum()), holding framesDone frames. */
   writeSum(sum, framesDone) { this.addon.writeSum(this.handle, this.width, this.height, sum, framesDone); }
