@@ -39,6 +39,13 @@ CASES = {
     "my_cornell_6_prog_b1": ("my_cornell_6", 48, 48, 4, 1, [1000, 1001, 1002, 1003, 1004]),
     "pixar_room_prog_b1": ("pixar_room", 48, 27, 4, 1, [1000, 1001, 1002, 1003]),
     "my_cornell_6_tall_prog_b1": ("my_cornell_6", 24, 40, 4, 1, [1000, 1001, 1002, 1003]),
+    # deeper paths on every scene (sin/cos, NaN slabs, Russian roulette), wide and tall, single and progressive
+    "teapot_b8": ("teapot", 64, 36, 8, 8, [1000]),
+    "bedroom2_v5_b4": ("bedroom2_v5", 64, 36, 8, 4, [1000, 1001]),
+    "my_cornell_6_wide_b8": ("my_cornell_6", 64, 36, 8, 8, [1000]),
+    "my_cornell_6_tall_b12": ("my_cornell_6", 24, 40, 4, 12, [1001]),
+    "pixar_room_prog_b4": ("pixar_room", 48, 27, 4, 4, [1000, 1001, 1002]),
+    "cornell_prog_b4": ("cornell", 40, 40, 4, 4, [2000, 2001, 2002]),
 }
 
 
