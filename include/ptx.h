@@ -144,12 +144,15 @@ int ptx_frames_done(const ptx_ctx *ctx); /* frames accumulated so far (negative 
 int ptx_read_linear_f32(ptx_ctx *ctx, float *rgb);
 /* rgb: W*H*3 floats: the raw sum over frames (what the multi-GPU all-reduce adds up). */
 int ptx_read_sum_f32(ptx_ctx *ctx, float *rgb);
-/* out: W*H*4 bytes. apply_gamma: pow(c, 1/2.2) as shaders/fragmentShaderOutput.glsl:35; flip_y: the
- * vertical flip of main.js:464-473 (row 0 = top row). Quantisation: floor(c*255 + 0.5). */
+/* out: W*H*4 bytes. apply_gamma: pow(c, 1/2.2) as shaders/fragmentShaderOutput.glsl:35 (pow = exp2(y * log2(x)) in the
+ * operation sequence of the arithmetic contract); flip_y: the vertical flip of main.js:464-473
+ * (row 0 = top row). Quantisation: floor(c*255 + 0.5). */
 int ptx_read_rgba8(ptx_ctx *ctx, uint8_t *out, int apply_gamma, int flip_y);
 
-/* The reference's RGBA8 ping-pong target after the last frame (option "compat_rgba8" = 1): what gl.readPixels (main.js:459)
- * returns in the browser, for frame-by-frame comparison with captures.  apply_gamma / flip_y as ptx_read_rgba8. */
+/* The reference's RGBA8 ping-pong target after the last frame (option "compat_rgba8" = 1 or 2).  With apply_gamma it is
+ * passed through the display pass (fragmentShaderOutput.glsl over the 8-bit target, main.js:357-373): what gl.readPixels
+ * (main.js:459) returns in the browser, for frame-by-frame comparison with captures; the 8-bit store of the display pass
+ * follows the same rule set as the option.  flip_y as ptx_read_rgba8. */
 int ptx_read_compat_rgba8(ptx_ctx *ctx, uint8_t *out, int apply_gamma, int flip_y);
 /* Checkpoint restore (new): sets the accumulation to rgb (W*H*3 floats as written by ptx_read_sum_f32) and
  * the frame count to frames_done, so a long progressive render (main.js:391-436 renderAsync) can resume after a restart. */

@@ -46,6 +46,11 @@ CASES = {
     "my_cornell_6_tall_b12": ("my_cornell_6", 24, 40, 4, 12, [1001]),
     "pixar_room_prog_b4": ("pixar_room", 48, 27, 4, 4, [1000, 1001, 1002]),
     "cornell_prog_b4": ("cornell", 40, 40, 4, 4, [2000, 2001, 2002]),
+    # "_disp_": the reference's display pass (fragmentShaderOutput.glsl: pow(c, 1/2.2)) drawn into the canvas after every
+    # frame as main.js:357-373 does; the canvas pixels are stored as `display` next to the 8-bit targets
+    "my_cornell_6_disp_prog_b4": ("my_cornell_6", 48, 48, 4, 4, [1000, 1001, 1002]),
+    "pixar_room_disp_b8": ("pixar_room", 64, 36, 8, 8, [1000]),
+    "bedroom2_v5_disp_prog_b1": ("bedroom2_v5", 24, 40, 4, 1, [1000, 1001]),
 }
 
 
@@ -125,7 +130,8 @@ def run_prim_case(name):
 # (the tail of main() computes them from pixel indices and uniforms; nothing of the scene is used):
 #   sincos: float bits of theta = 2 pi i / 16384, sin(theta), cos(theta), sqrt(i / 16384) for i = 0 .. 16383
 #   minmax: min/max with NaN and infinite operands (NaN = 0 * (1 / 0) built from the uniform maxPathLength = 0)
-PROBE_CASES = {"sincos": 128, "minmax": 4}
+#   pow:    float bits of x = i / 16384, pow(x, 1 / 2.2) (the display pass, fragmentShaderOutput.glsl:35), log2(x), exp2(-16 x)
+PROBE_CASES = {"sincos": 128, "minmax": 4, "pow": 128}
 MINMAX_EXPR = ["min(qn, one)", "min(one, qn)", "max(qn, one)", "max(one, qn)", "min(ninf, qn)", "max(ninf, qn)", "min(qn, ninf)", "max(qn, ninf)",
                "nan2", "min(nan2, one)", "min(one, nan2)", "max(nan2, one)", "max(one, nan2)", "pinf", "ninf", "(qn <= one) ? 1.0f : 0.0f"]
 
@@ -143,6 +149,11 @@ def run_probe_case(name):
         nwords = 4
         probe = ("    uint idx = uint(gl_FragCoord.y) * %du + uint(gl_FragCoord.x);\n    float rr = float(idx) * %sf;\n    float th = 2.0f * M_PI * rr;\n"
                  "    uint w = debugWord == 0 ? floatBitsToUint(th) : (debugWord == 1 ? floatBitsToUint(sin(th)) : (debugWord == 2 ? floatBitsToUint(cos(th)) : floatBitsToUint(sqrt(rr))));"
+                 % (w, repr(1.0 / (w * h))))
+    elif name == "pow":
+        nwords = 4
+        probe = ("    uint idx = uint(gl_FragCoord.y) * %du + uint(gl_FragCoord.x);\n    float rr = float(idx) * %sf;\n"
+                 "    float dv[4] = float[4](rr, pow(rr, 1.0 / 2.2), log2(rr), exp2(-16.0f * rr));\n    uint w = floatBitsToUint(dv[debugWord]);"
                  % (w, repr(1.0 / (w * h))))
     else:
         nwords = len(MINMAX_EXPR)
@@ -162,6 +173,9 @@ def run_probe_case(name):
     os.makedirs(PRIM_OUT, exist_ok=True)
     if name == "sincos":
         np.savez_compressed(os.path.join(PRIM_OUT, "probe_sincos.npz"), theta_bits=words[0], sin_bits=words[1], cos_bits=words[2], sqrt_bits=words[3],
+                            renderer=json.dumps(res["info"]))
+    elif name == "pow":
+        np.savez_compressed(os.path.join(PRIM_OUT, "probe_pow.npz"), x_bits=words[0], pow_bits=words[1], log2_bits=words[2], exp2_bits=words[3],
                             renderer=json.dumps(res["info"]))
     else:
         np.savez_compressed(os.path.join(PRIM_OUT, "probe_minmax.npz"), expr=np.asarray(MINMAX_EXPR), bits=words[:, 0], renderer=json.dumps(res["info"]))
@@ -203,11 +217,19 @@ def run_case(name):
         "scene": {"T": s.T, "N": s.N, "L": s.L, **{k: getattr(s, k).tolist() for k in
                   ("coords", "normals", "colors", "emissions", "light_tri", "node_min", "node_max", "node_miss", "node_first", "node_count", "inorder_tri")}},
     }
+    if "_disp_" in name:
+        out_text = open(os.path.join(REF, "fragmentShaderOutput.glsl")).read()
+        # the file opens with a comment line BEFORE '#version 300 es', which GLSL ES rejects ("#version directive must occur
+        # on the first line"; the reference's bundler evidently strips it): drop the lines in front of the directive
+        payload["outputFragmentShader"] = out_text[out_text.index("#version"):]
     t0 = time.time()
     res = call_harness(name, payload)
     frames = np.stack([np.frombuffer(base64.b64decode(b), dtype=np.uint8).reshape(h, w, 4) for b in res["frames"]])
     os.makedirs(OUT, exist_ok=True)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), frames=frames, scene=scene_name, width=w, height=h, sample_count=spp,
+    extra = {}
+    if "_disp_" in name:
+        extra["display"] = np.stack([np.frombuffer(base64.b64decode(b), dtype=np.uint8).reshape(h, w, 4) for b in res["display"]])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), frames=frames, scene=scene_name, **extra, width=w, height=h, sample_count=spp,
                         max_path_length=bounces, timestamps=np.asarray(ts, dtype=np.int32), draw_ms=np.asarray(res["ms"]),
                         renderer=json.dumps(res["info"]), host_cores=os.cpu_count())
     print(name, res["info"], "draw ms", [round(x) for x in res["ms"]], "wall", round(time.time() - t0, 1), "s", flush=True)

@@ -187,5 +187,19 @@ def blend_rgba8(p, cur_rgb, prev_rgba8, frame_number, store=0):
     return out
 
 
+def pow_(x, y):
+    lib().orc_pow.restype = C.c_float
+    return float(lib().orc_pow(C.c_float(x), C.c_float(y)))
+
+
+def display_rgba8(rgba8, store=0):
+    """The reference's display pass over an 8-bit target (gamma 1/2.2); store as in blend_rgba8."""
+    src = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    out = np.zeros_like(src)
+    lib().orc_display_rgba8(src.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint32(src.shape[0] * src.shape[1]), C.c_int32(store),
+                            out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
 def max_threads():
     return int(lib().orc_max_threads())

@@ -487,6 +487,48 @@ static inline uint8_t to_unorm8(float c, int store) {
     return (uint8_t)floorf(clamp01(c) * 255.0f + 0.5f);
 }
 
+/* pow(x, y) of the display pass (shaders/fragmentShaderOutput.glsl:35).  GLSL leaves the precision of pow open; the contract
+ * is the operation sequence the implementation the reference is run on here evaluates, exp2(y * log2(x)) with the log2 and
+ * exp2 below -- every float bit of 16384 arguments reproduced (tests/golden/ref_prim/probe_pow.npz), every separately
+ * rounded.  log2: exponent and mantissa split, a (2,3) rational in the mantissa; exp2: floor split, degree-5 polynomial. */
+static inline float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float ss_log2(float x) {
+    const uint32_t xi = f_bits(x);
+    float x1 = bits_f(((xi & 0x7F800000u) >> 8) | 0x3F800000u);
+    x1 = (x1 - 1.4960938f) * 256.0f;                               /* the unbiased exponent */
+    const float m = bits_f((xi & 0x007FFFFFu) | 0x3F800000u);       /* mantissa in [1, 2) */
+    float x2 = (9.5428179e-2f * m + 4.7779095e-1f) * m + 1.9782813e-1f;
+    const float x3 = ((1.6618466e-2f * m + 2.0350508e-1f) * m + 2.7382900e-1f) * m + 4.0496687e-2f;
+    x2 = x2 / x3;
+    return x1 + (m - 1.0f) * x2;
+}
+static inline float ss_exp2(float x) {
+    float x0 = fmin_(x, bits_f(0x43010000u));                      /* 129 */
+    x0 = fmax_(x0, bits_f(0xC2FDFFFFu));                            /* -126.99999 */
+    const int32_t i = (int32_t)rintf(x0 - 0.5f);
+    const float ii = bits_f((uint32_t)(i + 127) << 23);
+    const float f = x0 - (float)i;
+    float ff = bits_f(0x3AF61905u);
+    ff = ff * f + bits_f(0x3C134806u);
+    ff = ff * f + bits_f(0x3D64AA23u);
+    ff = ff * f + bits_f(0x3E75EAD4u);
+    ff = ff * f + bits_f(0x3F31727Bu);
+    ff = ff * f + 1.0f;
+    return ii * ff;
+}
+float orc_pow(float x, float y) { return ss_exp2(y * ss_log2(x)); }
+
+/* The display pass over an 8-bit target (fragmentShaderOutput.glsl:22-41 drawn into the canvas, main.js:357-373):
+ * c = texel / 255, pow(c, 1 / 2.2), stored with the canvas' float -> unorm8 rule (store as in to_unorm8). */
+void orc_display_rgba8(const uint8_t *in_rgba8, uint32_t npix, int32_t store, uint8_t *out_rgba8) {
+    for (uint32_t i = 0; i < npix; i++) {
+        for (int k = 0; k < 3; k++)
+            out_rgba8[4 * (size_t)i + k] = to_unorm8(orc_pow((float)in_rgba8[4 * (size_t)i + k] / 255.0f, 1.0f / 2.2f), store);
+        out_rgba8[4 * (size_t)i + 3] = 255;
+    }
+}
+
 void orc_blend_rgba8(const orc_params *p, const float *cur_rgb, const uint8_t *prev_rgba8,
                      int32_t frame_number, uint8_t *out_rgba8) {
     orc_blend_rgba8_store(p, cur_rgb, prev_rgba8, frame_number, 0, out_rgba8);

@@ -120,6 +120,25 @@
     gl.enableVertexAttribArray(loc);
     gl.vertexAttribPointer(loc, 2, gl.FLOAT, false, 0, 0);
 
+    // p.outputFragmentShader: the reference's display pass (shaders/fragmentShaderOutput.glsl, verbatim) drawn into the canvas
+    // after every frame exactly as main.js:357-373 does (default framebuffer, the frame's target bound as u_texture, full
+    // viewport, clear, one TRIANGLE_STRIP), then gl.readPixels of the canvas like main.js:459 (before the row flip of :464-473)
+    var progOut = null, vaoOut = null, display = [];
+    if (p.outputFragmentShader) {
+      progOut = gl.createProgram();
+      gl.attachShader(progOut, compile(gl, gl.VERTEX_SHADER, p.vertexShader));
+      gl.attachShader(progOut, compile(gl, gl.FRAGMENT_SHADER, p.outputFragmentShader));
+      gl.linkProgram(progOut);
+      if (!gl.getProgramParameter(progOut, gl.LINK_STATUS)) throw new Error('link(output): ' + gl.getProgramInfoLog(progOut));
+      vaoOut = gl.createVertexArray();
+      gl.bindVertexArray(vaoOut);
+      gl.bindBuffer(gl.ARRAY_BUFFER, vb);
+      var locOut = gl.getAttribLocation(progOut, 'position');
+      gl.enableVertexAttribArray(locOut);
+      gl.vertexAttribPointer(locOut, 2, gl.FLOAT, false, 0, 0);
+      gl.bindVertexArray(vao);
+    }
+
     var frames = [], times = [];
     // p.debug_words: a DERIVED shader (built by gen_ref_frames.py from the reference text at run time) writes one 32-bit word
     // per pixel as four bytes; one draw per word, selected by the uniform debugWord
@@ -143,8 +162,23 @@
       gl.readPixels(0, 0, p.width, p.height, gl.RGBA, gl.UNSIGNED_BYTE, px);
       times.push(performance.now() - t0);
       frames.push(b64(px));
+      if (progOut) {
+        gl.bindFramebuffer(gl.FRAMEBUFFER, null);
+        gl.useProgram(progOut);
+        gl.bindVertexArray(vaoOut);
+        gl.activeTexture(gl.TEXTURE0 + (n % 2)); gl.bindTexture(gl.TEXTURE_2D, tex[n % 2]);
+        gl.uniform1i(gl.getUniformLocation(progOut, 'u_texture'), n % 2);
+        gl.viewport(0, 0, p.width, p.height);
+        gl.clear(gl.COLOR_BUFFER_BIT);
+        gl.drawArrays(gl.TRIANGLE_STRIP, 0, 4);
+        var dpx = new Uint8Array(p.width * p.height * 4);
+        gl.readPixels(0, 0, p.width, p.height, gl.RGBA, gl.UNSIGNED_BYTE, dpx);
+        display.push(b64(dpx));
+        gl.useProgram(prog);
+        gl.bindVertexArray(vao);
+      }
     }
-    return { info: info, frames: frames, ms: times, glError: gl.getError() };
+    return { info: info, frames: frames, display: display, ms: times, glError: gl.getError() };
   }
 
   window.Plotly = {

@@ -78,6 +78,34 @@ __device__ __forceinline__ void sincos_2pi(float theta, float& s, float& c) {
     c = ss_sin(theta + 1.57079632f);
 }
 
+// pow(x, y) of the display pass (fragmentShaderOutput.glsl:35): the contract's operation sequence (oracle/ptx_oracle.c ss_log2,
+// ss_exp2, orc_pow; pinned by tests/golden/ref_prim/probe_pow.npz): exp2(y * log2(x)), every op separately rounded.
+__device__ __forceinline__ float ss_log2(float x) {
+    const uint32_t xi = __float_as_uint(x);
+    float x1 = __uint_as_float(((xi & 0x7F800000u) >> 8) | 0x3F800000u);
+    x1 = (x1 - 1.4960938f) * 256.0f;
+    const float m = __uint_as_float((xi & 0x007FFFFFu) | 0x3F800000u);
+    float x2 = (9.5428179e-2f * m + 4.7779095e-1f) * m + 1.9782813e-1f;
+    const float x3 = ((1.6618466e-2f * m + 2.0350508e-1f) * m + 2.7382900e-1f) * m + 4.0496687e-2f;
+    x2 = x2 / x3;
+    return x1 + (m - 1.0f) * x2;
+}
+__device__ __forceinline__ float ss_exp2(float x) {
+    float x0 = x < __uint_as_float(0x43010000u) ? x : __uint_as_float(0x43010000u);          // min, max: second operand on NaN
+    x0 = x0 > __uint_as_float(0xC2FDFFFFu) ? x0 : __uint_as_float(0xC2FDFFFFu);
+    const int i = (int)__builtin_rintf(x0 - 0.5f);
+    const float ii = __uint_as_float((uint32_t)(i + 127) << 23);
+    const float f = x0 - (float)i;
+    float ff = __uint_as_float(0x3AF61905u);
+    ff = ff * f + __uint_as_float(0x3C134806u);
+    ff = ff * f + __uint_as_float(0x3D64AA23u);
+    ff = ff * f + __uint_as_float(0x3E75EAD4u);
+    ff = ff * f + __uint_as_float(0x3F31727Bu);
+    ff = ff * f + 1.0f;
+    return ii * ff;
+}
+__device__ __forceinline__ float ss_pow(float x, float y) { return ss_exp2(y * ss_log2(x)); }
+
 // glsl:315-337
 __device__ __forceinline__ V3 sample_hemisphere(float r0, float r1, V3 n) {
     float theta = (2.0f * PTX_M_PI) * r0;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_pack_rgba8(const float4* __restrict__ a
     unsigned char q[3];
     for (int k = 0; k < 3; k++) {
         float cval = clamp01(v[k]);
-        if (apply_gamma) cval = powf(cval, 1.0f / 2.2f);
+        if (apply_gamma) cval = ss_pow(cval, 1.0f / 2.2f);
         q[k] = (unsigned char)floorf(clamp01(cval) * 255.0f + 0.5f);
     }
     const uint32_t oy = flip_y ? (H - 1 - y) : y;
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void k_blend_rgba8(const uchar4* __restrict__ 
 }
 
 // display pass over the 8-bit target (shaders/fragmentShaderOutput.glsl:35) + optional flip (main.js:464-473)
-__global__ __launch_bounds__(256) void k_display_rgba8(const uchar4* __restrict__ in, uint32_t W, uint32_t H, int apply_gamma, int flip_y,
+// rules: the canvas' float -> 8-bit store, as in k_blend_rgba8 (1 = round to nearest, 2 = SwiftShader's 16-bit intermediate)
+__global__ __launch_bounds__(256) void k_display_rgba8(const uchar4* __restrict__ in, uint32_t W, uint32_t H, int apply_gamma, int flip_y, int rules,
                                                        uchar4* __restrict__ out) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= W * H) return;
@@ -149,7 +150,15 @@ __global__ __launch_bounds__(256) void k_display_rgba8(const uchar4* __restrict_
     const uchar4 q = in[p];
     unsigned char o[3] = {q.x, q.y, q.z};
     if (apply_gamma)
-        for (int k = 0; k < 3; k++) o[k] = (unsigned char)floorf(clamp01(powf((float)o[k] / 255.0f, 1.0f / 2.2f)) * 255.0f + 0.5f);
+        for (int k = 0; k < 3; k++) {
+            const float g = clamp01(ss_pow((float)o[k] / 255.0f, 1.0f / 2.2f));
+            if (rules == 2) {
+                const uint32_t c16 = (uint32_t)(g * 65535.0f);
+                o[k] = (unsigned char)((c16 - (c16 >> 8) + 0x80u) >> 8);
+            } else {
+                o[k] = (unsigned char)floorf(g * 255.0f + 0.5f);
+            }
+        }
     const uint32_t oy = flip_y ? (H - 1 - y) : y;
     out[(size_t)oy * W + x] = make_uchar4(o[0], o[1], o[2], 255);
 }
@@ -902,7 +911,7 @@ extern "C" int ptx_read_compat_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma
     uchar4* d_out = nullptr;
     HIP_TRY(ctx, hipMalloc(&d_out, npix * sizeof(uchar4)));
     hipLaunchKernelGGL(k_display_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur], ctx->P.W, ctx->P.H,
-                       apply_gamma, flip_y, d_out);
+                       apply_gamma, flip_y, ctx->opt_compat, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, npix * sizeof(uchar4), hipMemcpyDeviceToHost);

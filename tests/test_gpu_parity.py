@@ -337,9 +337,13 @@ def test_accumulation_semantics(gpu_ctx, ptx, orc):
     assert (bits(gpu_ctx.read_sum()) == bits(want)).all()
     lin = gpu_ctx.read_linear()
     assert (bits(lin) == bits((want / np.float32(7)).astype(np.float32))).all()
-    # display pass: pow(c, 1/2.2), unorm8, flip (fragmentShaderOutput.glsl:35, main.js:464-473); pow is not exactly
-    # rounded on either side -> +-1 code value
+    # display pass: pow(c, 1/2.2), unorm8, flip (fragmentShaderOutput.glsl:35, main.js:464-473); pow is the contract's
+    # operation sequence (oracle orc_pow, pinned by ref_prim/probe_pow.npz) -> equal to the oracle's, and within one code
+    # value of the exactly rounded power
     px = gpu_ctx.read_rgba8(apply_gamma=True, flip_y=True)
+    y = float(np.float32(1.0) / np.float32(2.2))
+    g = np.array([orc.pow_(float(v), y) for v in np.clip(lin, 0, 1).reshape(-1)], dtype=np.float32).reshape(lin.shape)
+    assert (px[..., :3] == np.floor(np.clip(g, 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint8)[::-1]).all()
     ref = np.floor(np.clip(lin.astype(np.float64), 0, 1) ** (1 / 2.2) * 255 + 0.5)[::-1]
     assert np.abs(px[..., :3].astype(np.int32) - ref.astype(np.int32)).max() <= 1 and (px[..., 3] == 255).all()
     raw = gpu_ctx.read_rgba8(apply_gamma=False, flip_y=False)

@@ -83,6 +83,19 @@ def test_sincos_sqrt_match_reference_implementation(orc):
     assert (np.sqrt((idx * F(1.0 / th.size)).astype(np.float32)).view(np.uint32) == z["sqrt_bits"]).all()      # sqrt: correctly rounded
 
 
+def test_pow_matches_reference_implementation(orc):
+    # ref_prim/probe_pow.npz: float bits of pow(x, 1/2.2) (the display pass, fragmentShaderOutput.glsl:35) for x = i / 16384
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_prim", "probe_pow.npz"))
+    assert "SwiftShader" in str(z["renderer"])
+    x = z["x_bits"].view(np.float32)
+    assert (x == (np.arange(x.size, dtype=np.float32) * F(1.0 / x.size)).astype(np.float32)).all()
+    y = float(F(1.0) / F(2.2))
+    got = np.array([orc.pow_(float(v), y) for v in x], dtype=np.float32)
+    assert (got.view(np.uint32) == z["pow_bits"]).all()
+    m = x > 0
+    assert np.abs(got[m] - x[m].astype(np.float64) ** (1 / 2.2)).max() < 3e-7
+
+
 def test_min_max_nan_rule_matches_reference_implementation(orc):
     # ref_prim/probe_minmax.npz: min/max with NaN operands on that implementation return the SECOND operand
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_prim", "probe_minmax.npz"))
