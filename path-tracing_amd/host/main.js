@@ -12,12 +12,15 @@
  *   node main.js --scene file.gltf|file.obj|file.ptxs [--camera preset | --camera-json file] [--width 256]
  *        [--height 256] [--frames 5] [--spp 5] [--bounces 5] [--out image.png|.ppm] [--dump-sum file.f32]
  *        [--device 0] [--traversal 0..3] [--save-scene out.ptxs] [--light-material name]
- *        [--checkpoint file.ptxc] [--checkpoint-every 16] [--compat-out image.png]
+ *        [--checkpoint file.ptxc] [--checkpoint-every 16] [--compat-out image.png [--compat-rules 1|2] [--compat-gamma 0|1]]
  * --checkpoint: progressive rendering like renderAsync (main.js:391-436): frames are rendered in batches of
  *   --checkpoint-every; after each batch {sum buffer, frames done} is written to the file (atomically, via rename).  If
  *   the file exists when the program starts, rendering resumes after the frames it holds (same size required); the
  *   timestamp of frame f is always 1000 + f, so a resumed render equals an uninterrupted one bit for bit.
- * --compat-out: also keep the reference's own RGBA8 ping-pong blend (glsl:532-552) and save it (no gamma, flipped).
+ * --compat-out: also keep the reference's own RGBA8 ping-pong blend (glsl:532-552) and save it, flipped like main.js:464-473.
+ *   --compat-gamma 1 passes it through the display pass first (fragmentShaderOutput.glsl): the image the reference saves.
+ *   --compat-rules: what GL leaves to the implementation (8-bit store, NEAREST on texel boundaries): 1 = preferred rules
+ *   (default), 2 = SwiftShader's, byte-identical to the reference run on SwiftShader (include/ptx.h, DESIGN.md section 4).
  */
 const fs = require('fs');
 const path = require('path');
@@ -63,7 +66,9 @@ function main() {
   if (a.traversal !== undefined) pt.setOption('traversal', a.traversal);
   if (a.compatOut) {
     if (a.checkpoint) throw new Error('--compat-out cannot be combined with --checkpoint (the 8-bit target is not checkpointed)');
-    pt.setOption('compat_rgba8', 1);
+    const rules = a.compatRules === undefined ? 1 : a.compatRules;
+    if (rules !== 1 && rules !== 2) throw new Error('--compat-rules must be 1 or 2');
+    pt.setOption('compat_rgba8', rules);
   }
   let first = 0;
   if (a.checkpoint && fs.existsSync(a.checkpoint)) {
@@ -92,7 +97,7 @@ function main() {
     console.log('wrote ' + a.out);
   }
   if (a.compatOut) {
-    const px = pt.readCompatRgba8(false, true);
+    const px = pt.readCompatRgba8(a.compatGamma === 1, true);
     (path.extname(a.compatOut) === '.ppm' ? writePPM : writePNG)(a.compatOut, px, a.width, a.height);
     console.log('wrote ' + a.compatOut);
   }

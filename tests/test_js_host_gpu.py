@@ -47,6 +47,18 @@ def test_node_cli_checkpoint_resume_and_compat_output(ptx, orc, tmp_path):
     png = str(tmp_path / "compat.png")
     subprocess.check_call(base + ["--frames", "3", "--compat-out", png])
     assert open(png, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    # the image the reference saves (progressive 8-bit blend, display pass, row flip) under SwiftShader's GL rules: equal to
+    # the oracle's blend + display chain, which tests/test_reference_frames.py pins byte for byte to the reference shaders
+    ppm = str(tmp_path / "compat.ppm")
+    subprocess.check_call(base + ["--frames", "3", "--compat-out", ppm, "--compat-rules", "2", "--compat-gamma", "1"])
+    raw = open(ppm, "rb").read()
+    head = ("P6\n%d %d\n255\n" % (w, h)).encode()
+    assert raw.startswith(head) and len(raw) == len(head) + w * h * 3
+    got8 = np.frombuffer(raw[len(head):], dtype=np.uint8).reshape(h, w, 3)
+    prev = None
+    for f, ts in enumerate(ptx.scene.timestamps(3)):
+        prev = orc.blend_rgba8(p, orc.render_frame(s, p, int(ts))[0], prev, f, store=1)
+    assert (got8 == orc.display_rgba8(prev, store=1)[::-1, :, :3]).all()
 
 
 @pytest.mark.gpu

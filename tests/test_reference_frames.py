@@ -95,7 +95,7 @@ def test_oracle_display_pass_matches_reference_shader(orc, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rules", [1, 2])
 @pytest.mark.parametrize("case", CASES)
-def test_gpu_matches_reference_shader(ptx, gpu_ctx, case, rules):
+def test_gpu_matches_reference_shader(ptx, orc, gpu_ctx, case, rules):
     ref, s, p = load(ptx, case)
     gpu_ctx.upload_scene(s)
     gpu_ctx.set_params(p)
@@ -123,8 +123,11 @@ def test_gpu_matches_reference_shader(ptx, gpu_ctx, case, rules):
     check(case, frames, ref, swiftshader_rules=(rules == 2))
     if "display" in ref.files:
         for f in range(len(shown)):
-            d = np.abs(shown[f].astype(np.int32) - ref["display"][f].astype(np.int32))
-            assert (d.max() == 0) if rules == 2 else (d.max() <= 2 and (d <= 1).mean() > 0.99), (case, f, rules, d.max())
+            if rules == 2:
+                assert (shown[f] == ref["display"][f]).all(), (case, f)                        # byte-identical to the canvas
+            # under either rule set: the display pass of the oracle over the library's own target (a +-1 difference of a
+            # dark texel becomes up to 21 code values after the gamma curve, so the canvas itself is no bound for rules = 1)
+            assert (shown[f] == orc.display_rgba8(frames[f], store=rules - 1)).all(), (case, f, rules)
 
 
 # ---------------------------------------------------------------- primary-ray words from the derived debug shader (ref_prim/)
