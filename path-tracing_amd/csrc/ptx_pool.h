@@ -33,6 +33,9 @@
 #define PTX_POOL_TRI_PRIO 3      // s_setprio of a wave while it runs a TRI phase (0 elsewhere)
 #endif
 
+#ifndef PTX_POOL_DEFER_CACHED
+#define PTX_POOL_DEFER_CACHED 1  // 1: one pass through shade_step per SHADE phase (cached primary hits wait for the next phase)
+#endif
 #ifndef PTX_POOL_MIN_WAVES
 #define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
 #endif
@@ -253,7 +256,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 }
                 bool act = run_shade;
                 int st = SH_TRACE;
-                while (__ballot(act) != 0ull) {
+                // PTX_POOL_DEFER_CACHED: a lane whose sample ended meets its cached primary hit in the NEXT shade phase, together
+                // with the other lanes that have a hit to process, instead of a second pass through shade_step for a few lanes now
+                for (int pass = 0; (PTX_POOL_DEFER_CACHED ? pass == 0 : true) && __ballot(act) != 0ull; pass++) {
                     LocalCnt cc = {};
                     if (act) {
                         if (cached) { t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri(); }
@@ -267,7 +272,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     w_att += (uint32_t)__popcll(__ballot(cc.light_attempts >= 1u));
                 }
                 bool done = false;
-                if (run_shade) {
+                if (run_shade && st == SH_CACHED) {            // (deferred) needs shade again: no ray in flight
+                    flags = (flags | F_CACHED) & ~F_TRAV;
+                } else if (run_shade) {
                     flags &= ~F_CACHED;
                     if (st == SH_DONE) {
                         const V3 rgb = path_result(P, p);
