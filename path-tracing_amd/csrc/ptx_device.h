@@ -209,7 +209,7 @@ __device__ __forceinline__ bool tri_test(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float&
     float v = f * dot(d, q);
     float t = f * dot(e2, q);
     t_out = t;
-    return !(a > -0.0001f && a < 0.0001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0001f);
+    return !(fabsf(a) < 0.0001f) && !(u < 0.0f || u > 1.0f) && !(v < 0.0f || u + v > 1.0f) && (t > 0.0001f);   // |a| < EPS == glsl:156 for every a, NaN included
 }
 
 // Two triangles A, B at once from a pair record (ptx_kernels.h "pairs"): every quantity is an f2 {A, B}, so the 48
@@ -221,7 +221,13 @@ __device__ __forceinline__ void tri_test2(V3 o, V3 d, float4 r0, float4 r1, floa
     const f2 dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
     const f2 hx = dy * e2z - e2y * dz, hy = dz * e2x - e2z * dx, hz = dx * e2y - e2x * dy;          // cross(d, e2)
     const f2 a = (e1x * hx + e1y * hy) + e1z * hz;
-    const f2 f = {rcp_det(a.x), rcp_det(a.y)};
+    f2 f;                                                  // rcp_det for both, with ONE (wave-uniformly rare) range check
+    if (__builtin_expect(fmaxf(fabsf(a.x), fabsf(a.y)) >= 0x1p100f, 0)) {
+        f = f2{1.0f / a.x, 1.0f / a.y};
+    } else {
+        const f2 r = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+        f = f2{fmaf(fmaf(-a.x, r.x, 1.0f), r.x, r.x), fmaf(fmaf(-a.y, r.y, 1.0f), r.y, r.y)};
+    }
     const f2 sx = f2{o.x, o.x} - v0x, sy = f2{o.y, o.y} - v0y, sz = f2{o.z, o.z} - v0z;
     const f2 u = f * ((sx * hx + sy * hy) + sz * hz);
     const f2 qx = sy * e1z - e1y * sz, qy = sz * e1x - e1z * sx, qz = sx * e1y - e1x * sy;          // cross(s, e1)
@@ -229,8 +235,9 @@ __device__ __forceinline__ void tri_test2(V3 o, V3 d, float4 r0, float4 r1, floa
     const f2 t = f * ((e2x * qx + e2y * qy) + e2z * qz);
     const f2 uv = u + v;
     tA = t.x; tB = t.y;
-    hitA = !(a.x > -0.0001f && a.x < 0.0001f) && !(u.x < 0.0f || u.x > 1.0f) && !(v.x < 0.0f || uv.x > 1.0f) && (t.x > 0.0001f);
-    hitB = !(a.y > -0.0001f && a.y < 0.0001f) && !(u.y < 0.0f || u.y > 1.0f) && !(v.y < 0.0f || uv.y > 1.0f) && (t.y > 0.0001f);
+    // glsl:156 'a > -EPS && a < EPS' is '|a| < EPS' for every a, NaN included (all three comparisons are false then)
+    hitA = !(fabsf(a.x) < 0.0001f) && !(u.x < 0.0f || u.x > 1.0f) && !(v.x < 0.0f || uv.x > 1.0f) && (t.x > 0.0001f);
+    hitB = !(fabsf(a.y) < 0.0001f) && !(u.y < 0.0f || u.y > 1.0f) && !(v.y < 0.0f || uv.y > 1.0f) && (t.y > 0.0001f);
 }
 
 } // namespace ptx
