@@ -63,7 +63,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     // the last chunk of the whole launch.
     uint32_t next = 0, last = 0;                                       // wave-uniform cursor into the current chunk
     bool exhausted = false;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // set bits of a ballot below this lane: v_mbcnt_lo/hi (two instructions, no mask registers)
+    auto below = [](unsigned long long m) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
 
     keys[lane] = PTX_POOL_KEY_NONE;
     unsigned long long cyc[3] = {0, 0, 0}, its[3] = {0, 0, 0};
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
             const bool ordered = S.oct_stride != 0u && __ballot(walking && (flags & F_INF)) == 0ull;
             auto walk = [&](auto MODE) {
+                bool w = walking;                                 // trav && i < N, carried from one step to the next
 #pragma nounroll
                 for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
                     if (tail - head > (uint32_t)(PTX_POOL_QCAP - 64)) break;
-                    const bool w = trav && i < N;
                     bool push = false;
                     uint32_t item = 0;
                     float tn = 0.f;
@@ -136,13 +137,14 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     }
                     const unsigned long long m = __ballot(push);
                     if (push) {
-                        const uint32_t pos = tail + (uint32_t)__popcll(m & lt_mask);
+                        const uint32_t pos = tail + below(m);
                         queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2((item & 0x00FFFFFFu) | (lane << 24), __float_as_uint(tn));
                         lastpos = pos + 1u;
                     }
                     tail += (uint32_t)__popcll(m);
                     if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
-                    if (__popcll(__ballot(trav && i < N)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
+                    w = trav && i < N;
+                    if (__popcll(__ballot(w)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
                 }
             };
             if (ordered) walk(std::integral_constant<int, 0>{});
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     if (base >= total) exhausted = true;
                     else { next = base; last = (total - base > chunk) ? base + chunk : total; }
                 }
-                const uint32_t mine = next + (uint32_t)__popcll(m & lt_mask);
+                const uint32_t mine = next + below(m);
                 const uint32_t avail = last - next;
                 next += min((uint32_t)__popcll(m), avail);
                 bool black = false;
