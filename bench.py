@@ -65,7 +65,8 @@ def cpu_baseline(m, scene, params, seconds_target=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=32)      # one launch of K frames per GPU: the drain at the end of a launch (about 40 ms
+                                                            # while the last paths finish) is amortised over the frames, as in a long render
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
