@@ -221,10 +221,14 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     if (mine >= last) {
                         if (exhausted) { flags = 0; want_task = false; }   // else: draws from the next chunk in the next round
                     } else {
-                        const uint32_t frame = mine / tasks_per_frame;
-                        const uint32_t r = mine - frame * tasks_per_frame;
+                        // task list: tile-major, frame-minor, the 64 pixels of a tile together: concurrently running waves work on
+                        // the same and on neighbouring tiles (measured against frame-major order: 93.9 -> 85.3 ms/frame at 4 frames
+                        // per launch, 83.4 -> 81.3 at 32)
+                        const uint32_t c64 = mine >> 6;
+                        const uint32_t tile = c64 / n_frames;
+                        const uint32_t frame = c64 - tile * n_frames;
                         uint32_t px, py;
-                        if (tile_pixel(P, r >> 6, r & 63u, px, py)) {      // else: padding lane of an edge tile, draw again
+                        if (tile_pixel(P, tile, mine & 63u, px, py)) {     // else: padding lane of an edge tile, draw again
                             const uint32_t pix = py * P.W + px;
                             L.sti(PW_PIX, (int)(pix | (frame << 26))); L.sti(PW_PACK, 0);
                             LocalCnt cb = {};

@@ -1,0 +1,22 @@
+"""ms/frame of a config against frames per launch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch  # noqa
+import numpy as np
+import ptx_import
+m = ptx_import.load()
+cfg = sys.argv[1] if len(sys.argv) > 1 else "headline"
+c = m.CONFIGS[cfg]
+s = m.load_scene(c["scene"]); p = m.config_params(c["scene"], c["width"], c["height"], c["sample_count"], c["max_path_length"])
+ctx = m.Context(0); ctx.upload_scene(s); ctx.set_params(p)
+ref = {}
+for order in (0,):
+    for n in (1, 4, 8, 32, 64):
+        ctx.reset_accum(); ctx.render_frames([999]); ctx.synchronize()     # warm (and, with order = 1, the cost map)
+        ctx.reset_accum()
+        t0 = time.time(); ctx.render_frames(list(range(1000, 1000 + n))); ctx.synchronize(); dt = time.time() - t0
+        img = ctx.read_sum()
+        if order == 0: ref[n] = img
+        else: assert (img.view(np.uint32) == ref[n].view(np.uint32)).all()
+        print(f"{cfg} frames/launch={n:3d} ms/frame={dt*1000/n:.1f}", flush=True)
