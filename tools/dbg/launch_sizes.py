@@ -12,11 +12,11 @@ s = m.load_scene(c["scene"]); p = m.config_params(c["scene"], c["width"], c["hei
 ctx = m.Context(0); ctx.upload_scene(s); ctx.set_params(p)
 ref = {}
 for order in (0,):
-    for n in (1, 4, 8, 32, 64):
+    for n in [int(x) for x in os.environ.get('LAUNCH_SIZES', '1,4,8,32,64').split(',')]:
         ctx.reset_accum(); ctx.render_frames([999]); ctx.synchronize()     # warm (and, with order = 1, the cost map)
         ctx.reset_accum()
         t0 = time.time(); ctx.render_frames(list(range(1000, 1000 + n))); ctx.synchronize(); dt = time.time() - t0
         img = ctx.read_sum()
         if order == 0: ref[n] = img
         else: assert (img.view(np.uint32) == ref[n].view(np.uint32)).all()
-        print(f"{cfg} frames/launch={n:3d} ms/frame={dt*1000/n:.1f}", flush=True)
+        print(f"{cfg} frames/launch={n:3d} ms/frame={dt*1000/n:.1f} total={dt*1000:.1f} ms", flush=True)
