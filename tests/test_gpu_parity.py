@@ -216,6 +216,21 @@ def test_edge_cases(gpu_ctx, ptx, orc):
             assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (pipeline, traversal)
 
 
+def test_task_list_shapes(gpu_ctx, ptx, orc):
+    """Pipeline 2's task list (tile-major, frame-minor, chunks drawn from a counter): ragged image sizes, frame counts that do
+    not divide anything, chunk sizes that are not multiples of a tile -- the sum never changes."""
+    for (w, h, nfr) in [(37, 19, 5), (8, 8, 7), (70, 9, 3)]:
+        s, p = setup(gpu_ctx, ptx, "my_cornell_6", w, h, spp=2, bounces=3)
+        ts = ptx.scene.timestamps(nfr)
+        want, _ = orc.render_frames(s, p, ts)
+        for chunk in (64, 1, 37, 640, 65536):
+            gpu_ctx.set_option("pool_chunk", chunk)
+            gpu_ctx.reset_accum()
+            gpu_ctx.render_frames(ts)
+            assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (w, h, nfr, chunk)
+    gpu_ctx.set_option("pool_chunk", 64)
+
+
 def collapse_tree(ptx, s, max_depth):
     """The same scene with every subtree below `max_depth` folded into one big leaf (leaf ranges are contiguous because the
     inorder list is the pre-order concatenation of the leaves): exercises leaf sizes the reference builder never makes."""
