@@ -429,7 +429,17 @@ static void sah_sample(const ptx_scene* sc, std::vector<SahNode>& tree) {
         tot += 0.5 * std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
         cum[t] = tot;
     }
-    if (!(tot > 0)) return;
+    auto finish = [&]() {
+        for (size_t x = 0; x < n; x++) {
+            double prior = 1.0;                                    // surface-area ratio, worth 8 pseudo-observations
+            if (tree[x].parent >= 0) {
+                const double pa = half_area(tree[tree[x].parent].mn, tree[tree[x].parent].mx);
+                prior = pa > 0 ? std::min(1.0, half_area(tree[x].mn, tree[x].mx) / pa) : 1.0;
+            }
+            tree[x].q = ((double)ent[x] + 8.0 * prior) / ((double)vis[x] + 8.0);
+        }
+    };
+    if (!(tot > 0)) { finish(); return; }                          // no area to sample from: surface-area ratios alone
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
     struct Ray { double o[3], d[3], inv[3]; double best, limit; };
@@ -502,14 +512,7 @@ static void sah_sample(const ptx_scene* sc, std::vector<SahNode>& tree) {
             }
         }
     }
-    for (size_t x = 0; x < n; x++) {
-        double prior = 1.0;                                        // surface-area ratio, worth 8 pseudo-observations
-        if (tree[x].parent >= 0) {
-            const double pa = half_area(tree[tree[x].parent].mn, tree[tree[x].parent].mx);
-            prior = pa > 0 ? std::min(1.0, half_area(tree[x].mn, tree[x].mx) / pa) : 1.0;
-        }
-        tree[x].q = ((double)ent[x] + 8.0 * prior) / ((double)vis[x] + 8.0);
-    }
+    finish();
 }
 
 // Contraction: an inner node whose box is almost always hit when its parent's is costs a test and rejects nothing; leaving
@@ -589,7 +592,7 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n
     sah_sample(sc, tree);
     SahPlan pl;
     pl.tree = &tree;
-    pl.bias = PTX_SAH_CONTRACT_BIAS;
+    pl.bias = tree.size() <= (1u << 20) ? PTX_SAH_CONTRACT_BIAS : 0.0;   // the plan keeps (node, ancestor) states: bounded here
     sah_plan(pl, 0, -1);
     out.clear();
     out.reserve(tree.size() * 16);
