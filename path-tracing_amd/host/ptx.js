@@ -20,6 +20,17 @@ class PathTracer {
     this.addon = loadAddon();
     this.handle = this.addon.create(device || 0);
     this.width = 0; this.height = 0;
+    this._busy = false;
+    // one context, one thread: while an async render runs on the libuv pool, calls from the event loop are refused
+    for (const name of Object.getOwnPropertyNames(PathTracer.prototype)) {
+      if (name === 'constructor' || name === 'renderFramesAsync' || name === 'framesDone') continue;
+      const fn = this[name];
+      if (typeof fn !== 'function') continue;
+      this[name] = (...args) => {
+        if (this._busy) throw new Error('ptx: ' + name + '() while renderFramesAsync is running; await its promise first');
+        return fn.apply(this, args);
+      };
+    }
   }
 
   /** scene: the typed arrays of host/scene.js buildSceneArrays() (or scenefile.readScene()). */
@@ -38,8 +49,15 @@ class PathTracer {
   /** timestamps: one int per frame (uniform `timestamp`, main.js:300). Blocks until the frames are done. */
   renderFrames(timestamps, firstFrameNumber) { this.addon.renderFrames(this.handle, Int32Array.from(timestamps), firstFrameNumber || 0); }
   /** Same, without blocking the event loop (the reference's frame loop is async, main.js:391): resolves when the frames are
-   *  done.  Do not call anything else on this PathTracer until the promise has settled. */
-  renderFramesAsync(timestamps, firstFrameNumber) { return this.addon.renderFramesAsync(this.handle, Int32Array.from(timestamps), firstFrameNumber || 0); }
+   *  done.  The context is not thread-safe: until the promise has settled every other method of this PathTracer throws. */
+  renderFramesAsync(timestamps, firstFrameNumber) {
+    if (this._busy) return Promise.reject(new Error('ptx: a renderFramesAsync call is still running on this PathTracer'));
+    this._busy = true;
+    const done = () => { this._busy = false; };
+    let pr;
+    try { pr = this.addon.renderFramesAsync(this.handle, Int32Array.from(timestamps), firstFrameNumber || 0); } catch (e) { done(); throw e; }
+    return pr.then((v) => { done(); return v; }, (e) => { done(); throw e; });
+  }
   resetAccum() { this.addon.resetAccum(this.handle); }
   get framesDone() { return this.addon.framesDone(this.handle); }
   readLinear() { return this.addon.readLinear(this.handle, this.width, this.height); }

@@ -82,14 +82,18 @@ const cam = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_ri
   pt.resetAccum();
   let ticks = 0;
   const timer = setInterval(() => { ticks++; }, 1);
-  await pt.renderFramesAsync([1000, 1001, 1002], 0);
+  const pending = pt.renderFramesAsync([1000, 1001, 1002], 0);
+  let guarded = false, second = false;
+  try { pt.readSum(); } catch (e) { guarded = /while renderFramesAsync is running/.test(e.message); }   // one context, one thread
+  try { await pt.renderFramesAsync([1], 0); } catch (e) { second = /still running/.test(e.message); }
+  await pending;
   clearInterval(timer);
   const b = pt.readSum();
   let same = a.length === b.length;
   for (let i = 0; same && i < a.length; i++) same = Object.is(a[i], b[i]);
   let rejected = false;
   try { await pt.addon.renderFramesAsync(pt.handle, new Float32Array(2), 0); } catch (e) { rejected = true; }
-  console.log(JSON.stringify({ same, frames: pt.framesDone, rejected }));
+  console.log(JSON.stringify({ same, frames: pt.framesDone, rejected, guarded, second }));
   pt.destroy();
 })().catch((e) => { console.error(e); process.exit(1); });
 """ % ROOT
@@ -97,7 +101,7 @@ const cam = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_ri
     f.write_text(js)
     import json
     out = json.loads(subprocess.check_output(["node", str(f)]).decode().strip().splitlines()[-1])
-    assert out == {"same": True, "frames": 3, "rejected": True}
+    assert out == {"same": True, "frames": 3, "rejected": True, "guarded": True, "second": True}
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
