@@ -15,7 +15,6 @@
 #include <string>
 #include <vector>
 #include <limits>
-#include <map>
 
 using namespace ptx;
 
@@ -521,47 +520,54 @@ static void sah_sample(const ptx_scene* sc, std::vector<SahNode>& tree) {
 // `anc`, the cheaper of  keep: 1 + P(x entered | anc entered) * (children given x)  and  drop: children given anc.  The
 // probabilities are measured: sah_sample walks the uncontracted tree with sample rays of the kind a path tracer shoots.
 struct SahPlan {
+    enum { MAXD = 12 };                                            // a run of dropped ancestors is at most this long
     const std::vector<SahNode>* tree;
-    double bias;                                                   // > 1 favours keeping a node
-    std::map<std::pair<int, int>, std::pair<double, bool>> memo;   // (node, kept ancestor or -1) -> (expected tests, drop?)
+    double bias;                                                   // > 1 favours keeping a node; 0 keeps every node
+    std::vector<float> cost;                                       // (node, levels up to the kept ancestor) -> expected tests, < 0 = open
+    std::vector<uint8_t> drop;
+    void init(const std::vector<SahNode>* t, double b) { tree = t; bias = b; cost.assign(t->size() * (MAXD + 1), -1.0f); drop.assign(cost.size(), 0); }
 };
-static double sah_plan(SahPlan& pl, int x, int anc) {
-    const auto key = std::make_pair(x, anc);
-    const auto it = pl.memo.find(key);
-    if (it != pl.memo.end()) return it->second.first;
+// dist = levels between x and its nearest kept ancestor `anc` (1 = its parent; the root under "nothing kept above" counts 1)
+static double sah_plan(SahPlan& pl, int x, int anc, int dist, bool* dropped = nullptr) {
     const SahNode& nd = (*pl.tree)[x];
-    double cost = 1.0;
-    bool drop = false;
-    if (nd.left >= 0) {
-        double p = 1.0;                                            // P(x entered | anc entered): boxes are nested, so the
-        for (int y = x; y != anc && y >= 0; y = (*pl.tree)[y].parent) p *= (*pl.tree)[y].q;   // conditionals multiply along the chain
-        const double keep = 1.0 + p * (sah_plan(pl, nd.left, x) + sah_plan(pl, nd.right, x));
-        const double gone = sah_plan(pl, nd.left, anc) + sah_plan(pl, nd.right, anc);
-        drop = pl.bias > 0 && gone * pl.bias < keep;
-        cost = drop ? gone : keep;
+    if (nd.left < 0) { if (dropped) *dropped = false; return 1.0; }
+    const bool memo = dist <= SahPlan::MAXD;
+    const size_t key = (size_t)x * (SahPlan::MAXD + 1) + (size_t)(memo ? dist : 0);
+    if (memo && pl.cost[key] >= 0.0f) { if (dropped) *dropped = pl.drop[key] != 0; return pl.cost[key]; }
+    double p = 1.0;                                                // P(x entered | anc entered): boxes are nested, so the
+    for (int y = x; y != anc && y >= 0; y = (*pl.tree)[y].parent) p *= (*pl.tree)[y].q;   // conditionals multiply along the chain
+    const double keep = 1.0 + p * (sah_plan(pl, nd.left, x, 1) + sah_plan(pl, nd.right, x, 1));
+    bool d = false;
+    double c = keep;
+    if (pl.bias > 0 && memo && dist < SahPlan::MAXD) {
+        const double gone = sah_plan(pl, nd.left, anc, dist + 1) + sah_plan(pl, nd.right, anc, dist + 1);
+        if (gone * pl.bias < keep) { d = true; c = gone; }
     }
-    pl.memo[key] = std::make_pair(cost, drop);
-    return cost;
+    if (memo) { pl.cost[key] = (float)c; pl.drop[key] = d ? 1 : 0; }
+    if (dropped) *dropped = d;
+    return c;
 }
 
 // pre-order flattening of `tree` for rays whose direction signs are `oct` (bit k set = d[k] < 0): the child on the
 // side the ray comes from is visited first, so the threaded walk is roughly front-to-back and best-t pruning bites
 // early.  Which nodes are visited WITHOUT pruning does not depend on the order, so the hit leaves are unchanged.
-static void sah_flatten(const std::vector<SahNode>& tree, SahPlan& pl, int node, int anc, int oct, std::vector<float4>& out, size_t base) {
+static void sah_flatten(const std::vector<SahNode>& tree, SahPlan& pl, int node, int anc, int dist, int oct, std::vector<float4>& out, size_t base) {
     auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     const SahNode& nd = tree[node];
     const bool neg = (oct >> nd.axis) & 1;
-    if (nd.left >= 0 && (sah_plan(pl, node, anc), pl.memo[std::make_pair(node, anc)].second)) {   // dropped: children in its place
-        sah_flatten(tree, pl, neg ? nd.right : nd.left, anc, oct, out, base);
-        sah_flatten(tree, pl, neg ? nd.left : nd.right, anc, oct, out, base);
+    bool dropped = false;
+    sah_plan(pl, node, anc, dist, &dropped);
+    if (dropped) {                                                 // its children take its place
+        sah_flatten(tree, pl, neg ? nd.right : nd.left, anc, dist + 1, oct, out, base);
+        sah_flatten(tree, pl, neg ? nd.left : nd.right, anc, dist + 1, oct, out, base);
         return;
     }
     const size_t me = out.size() / 2 - base;
     out.push_back(make_float4(nd.mn[0], nd.mn[1], nd.mn[2], 0.f));
     out.push_back(make_float4(nd.mx[0], nd.mx[1], nd.mx[2], bits(nd.fc)));
     if (nd.left >= 0) {
-        sah_flatten(tree, pl, neg ? nd.right : nd.left, node, oct, out, base);
-        sah_flatten(tree, pl, neg ? nd.left : nd.right, node, oct, out, base);
+        sah_flatten(tree, pl, neg ? nd.right : nd.left, node, 1, oct, out, base);
+        sah_flatten(tree, pl, neg ? nd.left : nd.right, node, 1, oct, out, base);
     }
     out[2 * (base + me)].w = bits((int32_t)(out.size() / 2 - base));   // first pre-order index after this subtree (fixed below)
 }
@@ -591,18 +597,17 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n
     sah_build(items, ids, 0, ids.size(), tree);
     sah_sample(sc, tree);
     SahPlan pl;
-    pl.tree = &tree;
-    pl.bias = tree.size() <= (1u << 20) ? PTX_SAH_CONTRACT_BIAS : 0.0;   // the plan keeps (node, ancestor) states: bounded here
-    sah_plan(pl, 0, -1);
+    pl.init(&tree, PTX_SAH_CONTRACT_BIAS);
+    sah_plan(pl, 0, -1, 1);
     out.clear();
     out.reserve(tree.size() * 16);
-    sah_flatten(tree, pl, 0, -1, 0, out, 0);
+    sah_flatten(tree, pl, 0, -1, 1, 0, out, 0);
     const int32_t N2 = (int32_t)(out.size() / 2);                // nodes kept (the same set in every octant layout)
     out.clear();
     auto bits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
     for (int oct = 0; oct < 8; oct++) {
         const size_t base = (size_t)oct * N2;
-        sah_flatten(tree, pl, 0, -1, oct, out, base);
+        sah_flatten(tree, pl, 0, -1, 1, oct, out, base);
         for (int32_t i = 0; i < N2; i++) {
             int32_t m; std::memcpy(&m, &out[2 * (base + i)].w, 4);
             if (m >= N2) out[2 * (base + i)].w = bits(-1);
