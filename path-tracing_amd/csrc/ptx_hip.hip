@@ -193,6 +193,8 @@ struct ptx_ctx {
     size_t fb_frames = 0;
     int32_t* d_ts = nullptr;
     size_t ts_cap = 0;
+    void* d_stage = nullptr;                    // grow-only staging for read-backs and the trace hook (ensure_stage)
+    size_t stage_cap = 0;
 
     // options
     int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128, opt_compat = 0, opt_pool_chunk = 64;
@@ -295,6 +297,18 @@ static void free_params_buffers(ptx_ctx* ctx) {
     ctx->d_prim_t = nullptr; ctx->d_prim_tri = nullptr; ctx->d_accum = nullptr; ctx->d_fb = nullptr;
     ctx->fb_frames = 0;
     ctx->prim_valid = false;
+    ctx->have_params = false;                  // set again only once every buffer of the new size exists
+}
+
+// Grow-only device staging shared by the read-backs and ptx_trace_closest (one buffer, reused: no hipMalloc per call).
+static int ensure_stage(ptx_ctx* ctx, size_t bytes) {
+    if (ctx->stage_cap >= bytes) return PTX_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    ctx->d_stage = nullptr; ctx->stage_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_stage, bytes));
+    ctx->stage_cap = bytes;
+    return PTX_OK;
 }
 
 extern "C" void ptx_destroy(ptx_ctx* ctx) {
@@ -304,6 +318,7 @@ extern "C" void ptx_destroy(ptx_ctx* ctx) {
     free_scene(ctx);
     free_params_buffers(ctx);
     if (ctx->d_ts) (void)hipFree(ctx->d_ts);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_task_counter) (void)hipFree(ctx->d_task_counter);
     for (auto& pr : ctx->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -846,11 +861,10 @@ static int ensure_primary(ptx_ctx* ctx, float4* d_dirs) {
     return PTX_OK;
 }
 
-static hipEvent_t get_event(ptx_ctx* ctx) {
-    if (!ctx->free_events.empty()) { hipEvent_t e = ctx->free_events.back(); ctx->free_events.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
-    return e;
+static int get_event(ptx_ctx* ctx, hipEvent_t* out) {
+    if (!ctx->free_events.empty()) { *out = ctx->free_events.back(); ctx->free_events.pop_back(); return PTX_OK; }
+    HIP_TRY(ctx, hipEventCreate(out));
+    return PTX_OK;
 }
 
 static void drain_events(ptx_ctx* ctx) { // stream must be idle
@@ -863,26 +877,36 @@ static void drain_events(ptx_ctx* ctx) { // stream must be idle
     ctx->pending_events.clear();
 }
 
+// The device buffers one batch of frames renders through: the library's own allocations.
+struct RenderBufs {
+    float4* fb;               // nf x W*H clamp(mean) images of the batch
+    const int32_t* ts;        // nf timestamps of the batch
+    uint32_t* task_counter;   // pipeline 2: next undrawn task of the running launch
+};
+
 template <bool PRUNE, bool MEMO, bool COUNT>
-static void launch_render(ptx_ctx* ctx, uint32_t tiles, uint32_t nf) {
-    hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
-                       ctx->d_prim_tri, ctx->d_fb, ctx->d_counters);
+static hipError_t launch_render(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
+    const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
+    hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
+                       ctx->d_prim_tri, rb.fb, ctx->d_counters);
+    return hipGetLastError();
 }
 
 template <bool PRUNE, bool MEMO, bool COUNT>
-static void launch_render_wave(ptx_ctx* ctx, uint32_t nf) {
+static hipError_t launch_render_wave(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
-    const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32: ptx_render_frames caps the batch
+    const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32: render_frames_impl caps the batch
     const uint32_t per_wave = (uint32_t)ctx->opt_tasks_per_wave;
     const uint32_t blocks = (uint32_t)((total + per_wave - 1) / per_wave);
-    hipLaunchKernelGGL((k_render_wave<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
-                       ctx->d_prim_tri, ctx->d_fb, nf, per_wave, ctx->d_counters);
+    hipLaunchKernelGGL((k_render_wave<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
+                       ctx->d_prim_tri, rb.fb, nf, per_wave, ctx->d_counters);
+    return hipGetLastError();
 }
 
 template <bool PRUNE, bool MEMO, bool COUNT>
-static void launch_render_pool(ptx_ctx* ctx, uint32_t nf) {
+static hipError_t launch_render_pool(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
-    const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32 - 2^28: ptx_render_frames caps the batch
+    const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32 - 2^28: render_frames_impl caps the batch
     const uint32_t chunk = (uint32_t)ctx->opt_pool_chunk;
     uint64_t& resident = ctx->pool_resident[(PRUNE ? 4 : 0) | (MEMO ? 2 : 0) | (COUNT ? 1 : 0)];   // waves one residency of the chip holds
     if (resident == 0) {
@@ -892,9 +916,74 @@ static void launch_render_pool(ptx_ctx* ctx, uint32_t nf) {
         resident = (uint64_t)per_cu * (uint64_t)cus;   // any value is correct (waves draw work until none is left); this one fills the chip
     }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident, (total + chunk - 1) / chunk);
-    (void)hipMemsetAsync(ctx->d_task_counter, 0, sizeof(uint32_t), ctx->stream);
-    hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_ts, ctx->d_prim_t,
-                       ctx->d_prim_tri, ctx->d_fb, nf, chunk, ctx->d_task_counter, ctx->d_counters);
+    hipError_t e = hipMemsetAsync(rb.task_counter, 0, sizeof(uint32_t), ctx->stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
+                       ctx->d_prim_tri, rb.fb, nf, chunk, rb.task_counter, ctx->d_counters);
+    return hipGetLastError();
+}
+
+// the path-tracing kernel of the selected pipeline / traversal / memo / count options over one batch
+static hipError_t launch_path_tracer(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
+    const int sel = (opt_prune(ctx) ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
+    const int pipeline = (ctx->opt_pipeline == 2 && !ctx->pool_ok) ? 1 : ctx->opt_pipeline;
+#define PTX_SEL(fn)                                                   \
+    switch (sel) {                                                    \
+        case 0: return fn<false, false, false>(ctx, rb, nf);          \
+        case 1: return fn<false, false, true>(ctx, rb, nf);           \
+        case 2: return fn<false, true, false>(ctx, rb, nf);           \
+        case 3: return fn<false, true, true>(ctx, rb, nf);            \
+        case 4: return fn<true, false, false>(ctx, rb, nf);           \
+        case 5: return fn<true, false, true>(ctx, rb, nf);            \
+        case 6: return fn<true, true, false>(ctx, rb, nf);            \
+        default: return fn<true, true, true>(ctx, rb, nf);            \
+    }
+    if (pipeline == 2) { PTX_SEL(launch_render_pool) }
+    if (pipeline == 1) { PTX_SEL(launch_render_wave) }
+    PTX_SEL(launch_render)
+#undef PTX_SEL
+}
+
+// frames one launch may hold: pipelines 1 and 2 keep the frame-in-batch in 6 bits and index (pixel, frame) tasks with 32 bits
+static size_t cap_batch(const ptx_ctx* ctx, size_t batch) {
+    if (ctx->opt_pipeline != 0) batch = std::min<size_t>(batch, 64);
+    const uint64_t padded = (uint64_t)((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8) * 64u;
+    return std::max<size_t>(1, std::min<size_t>(batch, (size_t)(0xE0000000ull / padded)));
+}
+
+// one batch: path tracer into rb.fb, frame-order sum into the accumulation, optional RGBA8 compat blend
+static int render_batch(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf, uint32_t frame_number0, bool timed) {
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        if (ctx->pending_events.size() >= 64) {   // a caller that never synchronises: keep the event list bounded
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            drain_events(ctx);
+        }
+        int rc = get_event(ctx, &e0);
+        if (rc == PTX_OK && (rc = get_event(ctx, &e1)) != PTX_OK) ctx->free_events.push_back(e0);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(ctx, launch_path_tracer(ctx, rb, nf));
+    if (timed) {
+        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        ctx->pending_events.emplace_back(e0, e1);
+    }
+    ctx->kernel_launches++;
+    hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, rb.fb, (uint32_t)npix, nf);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->opt_compat) {   // the reference's own progressive blend, one frame after the other through the 8-bit targets
+        for (uint32_t f = 0; f < nf; f++) {
+            const float bf = 1.0f / (float)(frame_number0 + f + 1u);        // glsl:537: 1.0 / float(frameNumber + 1)
+            hipLaunchKernelGGL(k_blend_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur],
+                               rb.fb + (size_t)f * npix, ctx->d_compat[ctx->compat_cur ^ 1], ctx->P.W, ctx->P.H, ctx->P.aspect, bf, ctx->opt_compat);
+            ctx->compat_cur ^= 1;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->frames_done += nf;
+    return PTX_OK;
 }
 
 extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
@@ -909,12 +998,7 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
     // frames rendered concurrently: bounded by an 8 GiB frame-buffer budget (HBM is 288 GB) and 65535 grid.y
     size_t batch = ctx->opt_frame_batch > 0 ? (size_t)ctx->opt_frame_batch : std::min<size_t>(64, std::max<size_t>(1, (8ull << 30) / (npix * sizeof(float4))));
-    batch = std::min<size_t>(batch, n_frames);
-    if (ctx->opt_pipeline != 0) batch = std::min<size_t>(batch, 64);   // pipelines 1 and 2 keep the frame-in-batch in 6 bits
-    {   // pipeline 1 indexes (pixel, frame) tasks with 32 bits
-        const uint64_t padded = (uint64_t)((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8) * 64u;
-        batch = std::max<size_t>(1, std::min<size_t>(batch, (size_t)(0xE0000000ull / padded)));
-    }
+    batch = cap_batch(ctx, std::min<size_t>(batch, n_frames));
     if (ctx->fb_frames < batch) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_fb) (void)hipFree(ctx->d_fb);
@@ -929,73 +1013,19 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         HIP_TRY(ctx, hipMalloc(&ctx->d_ts, (size_t)n_frames * sizeof(int32_t)));
         ctx->ts_cap = n_frames;
     }
-    const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
+    if (ctx->opt_compat)
+        for (int k = 0; k < 2; k++)
+            if (!ctx->d_compat[k]) {
+                HIP_TRY(ctx, hipMalloc(&ctx->d_compat[k], npix * sizeof(uchar4)));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_compat[k], 0, npix * sizeof(uchar4), ctx->stream));
+            }
+    // all timestamps of the call in ONE copy (pageable source: the runtime stages it before returning, so the caller's array
+    // is free to go); earlier batches of this stream that still read d_ts are ordered before it
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ts, timestamps, (size_t)n_frames * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     for (uint32_t f0 = 0; f0 < n_frames; f0 += (uint32_t)batch) {
         const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
-        // pageable source: the runtime stages the copy before returning, so the caller's array is free to go
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ts, timestamps + f0, nf * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-        if (ctx->pending_events.size() >= 64) {   // a caller that never synchronises: keep the event list bounded
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            drain_events(ctx);
-        }
-        hipEvent_t e0 = get_event(ctx), e1 = get_event(ctx);
-        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
-        const int sel = (opt_prune(ctx) ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
-        const int pipeline = (ctx->opt_pipeline == 2 && !ctx->pool_ok) ? 1 : ctx->opt_pipeline;
-        if (pipeline == 2) {
-            switch (sel) {
-                case 0: launch_render_pool<false, false, false>(ctx, nf); break;
-                case 1: launch_render_pool<false, false, true>(ctx, nf); break;
-                case 2: launch_render_pool<false, true, false>(ctx, nf); break;
-                case 3: launch_render_pool<false, true, true>(ctx, nf); break;
-                case 4: launch_render_pool<true, false, false>(ctx, nf); break;
-                case 5: launch_render_pool<true, false, true>(ctx, nf); break;
-                case 6: launch_render_pool<true, true, false>(ctx, nf); break;
-                default: launch_render_pool<true, true, true>(ctx, nf); break;
-            }
-        } else if (pipeline == 1) {
-            switch (sel) {
-                case 0: launch_render_wave<false, false, false>(ctx, nf); break;
-                case 1: launch_render_wave<false, false, true>(ctx, nf); break;
-                case 2: launch_render_wave<false, true, false>(ctx, nf); break;
-                case 3: launch_render_wave<false, true, true>(ctx, nf); break;
-                case 4: launch_render_wave<true, false, false>(ctx, nf); break;
-                case 5: launch_render_wave<true, false, true>(ctx, nf); break;
-                case 6: launch_render_wave<true, true, false>(ctx, nf); break;
-                default: launch_render_wave<true, true, true>(ctx, nf); break;
-            }
-        } else
-        switch (sel) {
-            case 0: launch_render<false, false, false>(ctx, tiles, nf); break;
-            case 1: launch_render<false, false, true>(ctx, tiles, nf); break;
-            case 2: launch_render<false, true, false>(ctx, tiles, nf); break;
-            case 3: launch_render<false, true, true>(ctx, tiles, nf); break;
-            case 4: launch_render<true, false, false>(ctx, tiles, nf); break;
-            case 5: launch_render<true, false, true>(ctx, tiles, nf); break;
-            case 6: launch_render<true, true, false>(ctx, tiles, nf); break;
-            default: launch_render<true, true, true>(ctx, tiles, nf); break;
-        }
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-        ctx->pending_events.emplace_back(e0, e1);
-        ctx->kernel_launches++;
-        hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->d_fb, (uint32_t)npix, nf);
-        HIP_TRY(ctx, hipGetLastError());
-        if (ctx->opt_compat) {   // the reference's own progressive blend, one frame after the other through the 8-bit targets
-            for (int k = 0; k < 2; k++)
-                if (!ctx->d_compat[k]) {
-                    HIP_TRY(ctx, hipMalloc(&ctx->d_compat[k], npix * sizeof(uchar4)));
-                    HIP_TRY(ctx, hipMemsetAsync(ctx->d_compat[k], 0, npix * sizeof(uchar4), ctx->stream));
-                }
-            for (uint32_t f = 0; f < nf; f++) {
-                const float bf = 1.0f / (float)(first_frame_number + f0 + f + 1u);        // glsl:537: 1.0 / float(frameNumber + 1)
-                hipLaunchKernelGGL(k_blend_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur],
-                                   ctx->d_fb + (size_t)f * npix, ctx->d_compat[ctx->compat_cur ^ 1], ctx->P.W, ctx->P.H, ctx->P.aspect, bf, ctx->opt_compat);
-                ctx->compat_cur ^= 1;
-            }
-            HIP_TRY(ctx, hipGetLastError());
-        }
-        ctx->frames_done += nf;
+        const RenderBufs rb = {ctx->d_fb, ctx->d_ts + f0, ctx->d_task_counter};
+        if ((rc = render_batch(ctx, rb, nf, first_frame_number + f0, true))) return rc;
     }
     return PTX_OK;
 }
@@ -1043,14 +1073,14 @@ extern "C" int ptx_read_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int f
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
-    uchar4* d_out = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_out, npix * sizeof(uchar4)));
+    int rc = ensure_stage(ctx, npix * sizeof(uchar4));
+    if (rc) return rc;
+    uchar4* d_out = (uchar4*)ctx->d_stage;
     const float nf = (float)(ctx->frames_done ? ctx->frames_done : 1);
     hipLaunchKernelGGL(k_pack_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->P.W, ctx->P.H, nf, apply_gamma, flip_y, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, npix * sizeof(uchar4), hipMemcpyDeviceToHost);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_read_rgba8: ") + hipGetErrorString(e));
     drain_events(ctx);
     return PTX_OK;
@@ -1062,14 +1092,14 @@ extern "C" int ptx_read_compat_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma
     if (!ctx->d_compat[0]) return fail(ctx, PTX_ERR_STATE, "ptx_read_compat_rgba8: no frame was rendered with option compat_rgba8 = 1");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
-    uchar4* d_out = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_out, npix * sizeof(uchar4)));
+    int rc = ensure_stage(ctx, npix * sizeof(uchar4));
+    if (rc) return rc;
+    uchar4* d_out = (uchar4*)ctx->d_stage;
     hipLaunchKernelGGL(k_display_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur], ctx->P.W, ctx->P.H,
                        apply_gamma, flip_y, ctx->opt_compat, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, npix * sizeof(uchar4), hipMemcpyDeviceToHost);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_read_compat_rgba8: ") + hipGetErrorString(e));
     drain_events(ctx);
     return PTX_OK;
@@ -1095,13 +1125,15 @@ extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, u
     if (n == 0) return PTX_OK;
     if (!o || !d || !t || !tri_id) return fail(ctx, PTX_ERR_INVALID, "ptx_trace_closest: NULL array");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    float *d_o = nullptr, *d_d = nullptr, *d_t = nullptr;
-    int* d_tri = nullptr;
-    hipError_t e = hipMalloc(&d_o, (size_t)n * 12);
-    if (e == hipSuccess) e = hipMalloc(&d_d, (size_t)n * 12);
-    if (e == hipSuccess) e = hipMalloc(&d_t, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc(&d_tri, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMemcpy(d_o, o, (size_t)n * 12, hipMemcpyHostToDevice);
+    // staging: o | d | t | tri, each 256-B aligned inside the context's grow-only staging buffer
+    const size_t sz3 = (((size_t)n * 12 + 255) / 256) * 256, sz1 = (((size_t)n * 4 + 255) / 256) * 256;
+    int rc = ensure_stage(ctx, 2 * sz3 + 2 * sz1);
+    if (rc) return rc;
+    float* d_o = (float*)ctx->d_stage;
+    float* d_d = (float*)((char*)ctx->d_stage + sz3);
+    float* d_t = (float*)((char*)ctx->d_stage + 2 * sz3);
+    int* d_tri = (int*)((char*)ctx->d_stage + 2 * sz3 + sz1);
+    hipError_t e = hipMemcpy(d_o, o, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, d, (size_t)n * 12, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const uint32_t blocks = (n + 63) / 64;
@@ -1118,7 +1150,6 @@ extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, u
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tri_id, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_t); (void)hipFree(d_tri);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_trace_closest: ") + hipGetErrorString(e));
     return PTX_OK;
 }
@@ -1140,13 +1171,13 @@ extern "C" int ptx_primary_dirs(ptx_ctx* ctx, float* dirs) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "scene and params must be set first");
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
-    float4* d_dirs = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_dirs, npix * sizeof(float4)));
-    int rc = ensure_primary(ctx, d_dirs);
+    int rc = ensure_stage(ctx, npix * sizeof(float4));
+    if (rc) return rc;
+    float4* d_dirs = (float4*)ctx->d_stage;
+    rc = ensure_primary(ctx, d_dirs);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     std::vector<float4> h(npix);
     if (rc == PTX_OK && e == hipSuccess) e = hipMemcpy(h.data(), d_dirs, npix * sizeof(float4), hipMemcpyDeviceToHost);
-    (void)hipFree(d_dirs);
     if (rc) return rc;
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_primary_dirs: ") + hipGetErrorString(e));
     for (size_t i = 0; i < npix; i++) { dirs[3 * i] = h[i].x; dirs[3 * i + 1] = h[i].y; dirs[3 * i + 2] = h[i].z; }
