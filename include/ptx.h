@@ -134,6 +134,16 @@ int ptx_set_option(ptx_ctx *ctx, const char *key, int64_t value);
  * for the float accumulation: the running mean sum/frames_done equals the reference's mix(prev, cur, 1/(frameNumber+1))
  * chain (glsl:537-540) without its RGBA8 rounding; with option "compat_rgba8" it is the frameNumber of that chain.  Asynchronous: work is queued on the context's stream. */
 int ptx_render_frames(ptx_ctx *ctx, const int32_t *timestamps, uint32_t n_frames, uint32_t first_frame_number);
+/* The same rendering for callers that cannot allocate.  No counterpart in the reference: it is for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels and bit-identical results
+ * as ptx_render_frames, but every intermediate (the frame buffers of a batch, its timestamps, the task counter) lives in a
+ * file-scope static __device__ array of 64 MiB + 512 B per GPU (held until the process ends) instead of library
+ * allocations: the call makes no hipMalloc / hipFree / hipEventCreate and no host-to-device copy.  Limit: width * height
+ * <= 4 194 304 pixels (64 MiB / 16 B; frames are batched to fit), else PTX_ERR_INVALID with a message.  Scene and params
+ * must already be set (ptx_upload_scene / ptx_set_params allocate; this call does not); option "compat_rgba8" only if an
+ * earlier ptx_render_frames created its 8-bit targets.  The launches are not event-timed (ptx_counters.kernel_ms does
+ * not include them).  All contexts on one GPU share that GPU's array: calls that overlap on one GPU race. */
+int ptx_render_frames_noalloc(ptx_ctx *ctx, const int32_t *timestamps, uint32_t n_frames, uint32_t first_frame_number);
 int ptx_synchronize(ptx_ctx *ctx);
 /* Replaces gl.clear of the ping-pong targets (main.js:326-327) / starting a new progressive render. */
 int ptx_reset_accum(ptx_ctx *ctx);

@@ -21,7 +21,7 @@ _i = C.POINTER(C.c_int32)
 
 # every symbol include/ptx.h declares (tests check the library exports all of them)
 SYMBOLS = ["ptx_device_count", "ptx_create", "ptx_destroy", "ptx_last_error", "ptx_upload_scene", "ptx_set_params",
-           "ptx_set_option", "ptx_render_frames", "ptx_synchronize", "ptx_reset_accum", "ptx_frames_done",
+           "ptx_set_option", "ptx_render_frames", "ptx_render_frames_noalloc", "ptx_synchronize", "ptx_reset_accum", "ptx_frames_done",
            "ptx_read_linear_f32", "ptx_read_sum_f32", "ptx_read_rgba8", "ptx_read_compat_rgba8", "ptx_write_sum_f32", "ptx_trace_closest", "ptx_primary_hits",
            "ptx_primary_dirs", "ptx_get_counters", "ptx_reset_counters", "ptx_accum_export_device",
            "ptx_accum_import_device"]
@@ -87,6 +87,7 @@ def load_library():
     L.ptx_set_params.argtypes = [C.c_void_p, C.POINTER(CParams)]
     L.ptx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.ptx_render_frames.argtypes = [C.c_void_p, _i, C.c_uint32, C.c_uint32]
+    L.ptx_render_frames_noalloc.argtypes = [C.c_void_p, _i, C.c_uint32, C.c_uint32]
     L.ptx_synchronize.argtypes = [C.c_void_p]
     L.ptx_reset_accum.argtypes = [C.c_void_p]
     L.ptx_frames_done.argtypes = [C.c_void_p]
@@ -169,6 +170,11 @@ class Context:
     def render_frames(self, timestamps, first_frame_number=0):
         ts = np.ascontiguousarray(timestamps, dtype=np.int32)
         self._check(self._lib.ptx_render_frames(self._h, _ip(ts), ts.size, first_frame_number))
+
+    def render_frames_noalloc(self, timestamps, first_frame_number=0):
+        """ptx_render_frames through the static scratch: allocates nothing (include/ptx.h)."""
+        ts = np.ascontiguousarray(timestamps, dtype=np.int32)
+        self._check(self._lib.ptx_render_frames_noalloc(self._h, _ip(ts), ts.size, first_frame_number))
 
     def synchronize(self):
         self._check(self._lib.ptx_synchronize(self._h))

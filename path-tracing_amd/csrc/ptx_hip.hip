@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include <limits>
+#include <mutex>
 
 using namespace ptx;
 
@@ -163,6 +164,23 @@ __global__ __launch_bounds__(256) void k_display_rgba8(const uchar4* __restrict_
     out[(size_t)oy * W + x] = make_uchar4(o[0], o[1], o[2], 255);
 }
 
+// ---- static scratch of ptx_render_frames_noalloc: the entry point that allocates nothing (include/ptx.h)
+// One array per GPU the library runs on, held until the process ends: a 512-B header (task counter of pipeline 2 at byte 0,
+// the timestamps of one batch at byte 256) followed by the frame buffers of one batch.  In host code the name g_scratch is
+// only a stand-in for the symbol: the device address is taken per device with hipGetSymbolAddress (scratch_for_device) and
+// every use below goes through that pointer.
+#define PTX_SCRATCH_HEADER 512u
+#define PTX_SCRATCH_TS_OFFSET 256u
+#define PTX_SCRATCH_MAX_BATCH 64u                       // timestamps travel by value in one kernel argument block
+#define PTX_SCRATCH_FB_BYTES (64u << 20)                // 64 MiB = 4 194 304 (pixel, frame) results of 16 B
+static __device__ __align__(256) unsigned char g_scratch[PTX_SCRATCH_HEADER + PTX_SCRATCH_FB_BYTES];
+
+struct TsBlock { int32_t v[PTX_SCRATCH_MAX_BATCH]; };
+// timestamps of a batch, passed by value, into the scratch (no host-to-device copy, nothing to stage)
+__global__ __launch_bounds__(64) void k_store_timestamps(TsBlock ts, int32_t* __restrict__ dst, uint32_t n) {
+    if (threadIdx.x < n) dst[threadIdx.x] = ts.v[threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------ host side
 
 struct ptx_ctx {
@@ -193,6 +211,7 @@ struct ptx_ctx {
     size_t fb_frames = 0;
     int32_t* d_ts = nullptr;
     size_t ts_cap = 0;
+    unsigned char* d_scratch = nullptr;         // this device's copy of g_scratch (ptx_render_frames_noalloc); not owned
     void* d_stage = nullptr;                    // grow-only staging for read-backs and the trace hook (ensure_stage)
     size_t stage_cap = 0;
 
@@ -211,6 +230,24 @@ struct ptx_ctx {
 };
 
 static std::string g_create_error;
+
+// Device address of g_scratch on each GPU (every device holds its own copy of the array at its own address), taken once
+// per device in ptx_create with that device current.
+#define PTX_MAX_DEVICES 64
+static std::mutex g_scratch_mutex;
+static unsigned char* g_scratch_ptr[PTX_MAX_DEVICES] = {};
+static hipError_t scratch_for_device(int device, unsigned char** out) {   // `device` must be the current device
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (device < 0 || device >= PTX_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 // traversal option: bit 0 = best-t pruning, bit 1 = walk the leaf-SAH tree instead of the reference tree
 static inline bool opt_prune(const ptx_ctx* c) { return (c->opt_traversal & 1) != 0; }
@@ -273,7 +310,8 @@ extern "C" ptx_ctx* ptx_create(const int* device_ids, int n_devices) {
     if ((e = hipSetDevice(ctx->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc(&ctx->d_counters, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMalloc(&ctx->d_task_counter, sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMalloc(&ctx->d_task_counter, sizeof(uint32_t))) != hipSuccess ||
+        (e = scratch_for_device(ctx->device, &ctx->d_scratch)) != hipSuccess) {
         g_create_error = std::string("ptx_create: ") + hipGetErrorString(e);
         ptx_destroy(ctx);                  // releases whatever was created before the failing call
         return nullptr;
@@ -877,7 +915,8 @@ static void drain_events(ptx_ctx* ctx) { // stream must be idle
     ctx->pending_events.clear();
 }
 
-// The device buffers one batch of frames renders through: the library's own allocations.
+// The device buffers one batch of frames renders through: the library's own allocations (ptx_render_frames) or pieces of
+// the static scratch array (ptx_render_frames_noalloc).
 struct RenderBufs {
     float4* fb;               // nf x W*H clamp(mean) images of the batch
     const int32_t* ts;        // nf timestamps of the batch
@@ -1026,6 +1065,40 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
         const RenderBufs rb = {ctx->d_fb, ctx->d_ts + f0, ctx->d_task_counter};
         if ((rc = render_batch(ctx, rb, nf, first_frame_number + f0, true))) return rc;
+    }
+    return PTX_OK;
+}
+
+// The same rendering with every intermediate in the static scratch: no hipMalloc / hipFree / event creation, no copy from
+// host memory (timestamps go by value into k_store_timestamps).  Shares render_batch and all kernels with
+// ptx_render_frames.  All contexts on one GPU share that GPU's scratch: calls that overlap on one GPU race.
+extern "C" int ptx_render_frames_noalloc(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!timestamps && n_frames) return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames_noalloc: timestamps is NULL");
+    if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_render_frames_noalloc: scene and params must be set first");
+    if (!ctx->d_scratch) return fail(ctx, PTX_ERR_STATE, "ptx_render_frames_noalloc: no scratch on this device");
+    const size_t npix = (size_t)ctx->P.W * ctx->P.H;
+    const size_t cap = (size_t)PTX_SCRATCH_FB_BYTES / sizeof(float4);        // (pixel, frame) results the scratch holds
+    if (npix > cap)
+        return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames_noalloc: width * height = " + std::to_string(npix) + " exceeds the static scratch (" +
+                                              std::to_string(cap) + " pixels = 64 MiB of frame buffer); use ptx_render_frames");
+    if (ctx->opt_compat && (!ctx->d_compat[0] || !ctx->d_compat[1]))
+        return fail(ctx, PTX_ERR_STATE, "ptx_render_frames_noalloc: option compat_rgba8 needs its 8-bit targets, which only ptx_render_frames allocates");
+    if (n_frames == 0) return PTX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_primary(ctx, nullptr);
+    if (rc) return rc;
+    unsigned char* const base = ctx->d_scratch;                               // the device address, never the symbol's name
+    int32_t* const d_ts = (int32_t*)(base + PTX_SCRATCH_TS_OFFSET);
+    const RenderBufs rb = {(float4*)(base + PTX_SCRATCH_HEADER), d_ts, (uint32_t*)base};
+    const size_t batch = cap_batch(ctx, std::min<size_t>(std::min<size_t>(PTX_SCRATCH_MAX_BATCH, cap / npix), n_frames));
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += (uint32_t)batch) {
+        const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
+        TsBlock tb = {};
+        std::memcpy(tb.v, timestamps + f0, nf * sizeof(int32_t));
+        hipLaunchKernelGGL(k_store_timestamps, dim3(1), dim3(64), 0, ctx->stream, tb, d_ts, nf);
+        HIP_TRY(ctx, hipGetLastError());
+        if ((rc = render_batch(ctx, rb, nf, first_frame_number + f0, false))) return rc;   // untimed: creates no events
     }
     return PTX_OK;
 }
