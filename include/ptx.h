@@ -8,10 +8,12 @@
  * keeps ownership of everything it passes in; nothing here retains host pointers after returning.
  *
  * Conventions: functions return PTX_OK (0) or a negative ptx_status; the message of the last failure is
- * available from ptx_last_error().  No exception crosses the ABI.  A context is bound to ONE GPU and is
- * not thread-safe (the reference host is single-threaded JS, main.js:262,391).  Multi-GPU = one context
- * (one process) per GPU, each rendering its own frames, summed by the caller with one all-reduce of the
- * accumulation buffer (ptx_accum_export_device / ptx_accum_import_device; DESIGN.md "Multi-GPU").
+ * available from ptx_last_error().  No exception crosses the ABI.  A context is not thread-safe (the
+ * reference host is single-threaded JS, main.js:262,391).  Multi-GPU (DESIGN.md "Multi-GPU"): frames are
+ * split over the GPUs and the float accumulation buffers are summed by ONE all-reduce (RCCL over xGMI, loaded
+ * on first use) -- either inside one context created over several devices (ptx_create(device_ids, n > 1): the
+ * single-process form the Node host uses), or between one single-device context per process
+ * (ptx_comm_unique_id / ptx_comm_init / ptx_allreduce).
  * There is no CPU fallback: every entry point fails with PTX_ERR_HIP when no gfx950 device is usable.
  */
 #ifndef PTX_H
@@ -90,9 +92,19 @@ typedef struct ptx_counters {
 
 /* ---- lifecycle (no reference counterpart: canvas.getContext('webgl2'), main.js:123) ---- */
 int ptx_device_count(void);
-/* device_ids: HIP device ordinals; n_devices must be 1 (one context per GPU). Returns NULL on failure
- * (see ptx_last_error(NULL)). */
+/* device_ids: HIP device ordinals, n_devices in 1 .. 64.  n_devices == 1: a context bound to that GPU.  n_devices > 1:
+ * one context over several GPUs -- it replaces the single WebGL context of main.js:123 for a whole node: the scene and the
+ * parameters go to every device, ptx_render_frames deals the frames of each call round-robin (frame f of the call to device
+ * f mod n, over the full image), the devices render concurrently, and the first read-back after rendering sums the
+ * per-device accumulation buffers with one grouped ncclAllReduce (communicators from ncclCommInitAll).  The ids must be
+ * all distinct; the same id n times is accepted as a one-GPU rehearsal of the same code path (the sum is then taken by a
+ * kernel in device order, RCCL cannot put two ranks on one device).  Not available on a multi-device context: option
+ * "compat_rgba8" / ptx_read_compat_rgba8 (an 8-bit blend that is sequential over frames) and ptx_comm_init / ptx_allreduce.
+ * The float sum of n devices differs from a one-device render of the same frames only by the association of the
+ * additions.  Returns NULL on failure (see ptx_last_error(NULL)). */
 ptx_ctx *ptx_create(const int *device_ids, int n_devices);
+/* width and height of the last ptx_set_params (PTX_ERR_STATE before it): the size of every read-back buffer. */
+int ptx_get_size(const ptx_ctx *ctx, uint32_t *width, uint32_t *height);
 void ptx_destroy(ptx_ctx *ctx);
 const char *ptx_last_error(const ptx_ctx *ctx); /* ctx may be NULL: last creation error */
 
@@ -179,7 +191,24 @@ int ptx_primary_dirs(ptx_ctx *ctx, float *dirs);
 int ptx_get_counters(ptx_ctx *ctx, ptx_counters *out); /* synchronises */
 int ptx_reset_counters(ptx_ctx *ctx);
 
-/* ---- multi-process reduction hooks (new) ---- */
+/* ---- multi-GPU, one process per GPU (new; the reference has a single WebGL context, main.js:123) ----
+ * Rank r of G renders frames {r, r + G, ...} with ptx_render_frames on its own single-device context; ptx_allreduce then
+ * sums the accumulation buffers (W*H*4 f32; 33 MB at 1080p) and the frame counts of all ranks with one grouped
+ * ncclAllReduce on the context's stream.  The communicator is RCCL's own: rank 0 calls ptx_comm_unique_id and hands the
+ * 128 bytes to the other ranks over whatever channel the job has (torch.distributed, MPI, a file); every rank then calls
+ * ptx_comm_init (collective: ncclCommInitRank).  ptx_comm_world returns the rank count RCCL reports (0 = no communicator;
+ * the device count for a multi-device context). */
+#define PTX_COMM_ID_BYTES 128
+int ptx_comm_unique_id(void *id128);
+int ptx_comm_init(ptx_ctx *ctx, const void *id128, int rank, int world);
+int ptx_comm_world(const ptx_ctx *ctx);
+/* d_dst == NULL: in place -- afterwards every rank's accumulation is the total and ptx_frames_done the total count, so the
+ * read-backs give the same image on every rank (call it once, when the job's frames are rendered).  d_dst != NULL: the
+ * total goes to that device buffer (W*H*4 floats) and the rank's own accumulation is left alone (progress previews).
+ * frames_total (may be NULL) receives the summed frame count.  Blocks until the sum is there. */
+int ptx_allreduce(ptx_ctx *ctx, void *d_dst, uint32_t *frames_total);
+
+/* ---- reduction hooks for a caller that brings its own collective (new) ---- */
 /* Device-to-device copy of the W*H*4 f32 accumulation buffer (rgb sum + unused 4th lane) to / from
  * caller-owned device memory (e.g. a torch tensor that torch.distributed all-reduces over RCCL). */
 int ptx_accum_export_device(ptx_ctx *ctx, void *d_dst);

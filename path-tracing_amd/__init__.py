@@ -9,5 +9,5 @@ Python here is plumbing around the C-ABI library ``csrc/libptx_hip.so`` (include
 The product host is JavaScript (host/*.js + the raw N-API addon in csrc/ptx_napi.c).
 """
 from .scene import Scene, Params, load_scene, load_camera, config_params, CONFIGS  # noqa: F401
-from .binding import Context, PtxError, lib_path, load_library  # noqa: F401
-from .distributed import frames_for_rank, allreduce_sum, render_frames_distributed  # noqa: F401
+from .binding import Context, PtxError, lib_path, load_library, comm_unique_id  # noqa: F401
+from .distributed import frames_for_rank, allreduce_sum, render_frames_distributed, init_library_comm  # noqa: F401

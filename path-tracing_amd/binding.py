@@ -24,7 +24,7 @@ SYMBOLS = ["ptx_device_count", "ptx_create", "ptx_destroy", "ptx_last_error", "p
            "ptx_set_option", "ptx_render_frames", "ptx_render_frames_noalloc", "ptx_synchronize", "ptx_reset_accum", "ptx_frames_done",
            "ptx_read_linear_f32", "ptx_read_sum_f32", "ptx_read_rgba8", "ptx_read_compat_rgba8", "ptx_write_sum_f32", "ptx_trace_closest", "ptx_primary_hits",
            "ptx_primary_dirs", "ptx_get_counters", "ptx_reset_counters", "ptx_accum_export_device",
-           "ptx_accum_import_device"]
+           "ptx_accum_import_device", "ptx_get_size", "ptx_comm_unique_id", "ptx_comm_init", "ptx_comm_world", "ptx_allreduce"]
 
 
 class PtxError(RuntimeError):
@@ -103,8 +103,23 @@ def load_library():
     L.ptx_reset_counters.argtypes = [C.c_void_p]
     L.ptx_accum_export_device.argtypes = [C.c_void_p, C.c_void_p]
     L.ptx_accum_import_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.ptx_get_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ptx_comm_unique_id.argtypes = [C.c_void_p]
+    L.ptx_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.ptx_comm_world.argtypes = [C.c_void_p]
+    L.ptx_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     _LIB = L
     return L
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes it and hands it to the other ranks; Context.comm_init)."""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    rc = L.ptx_comm_unique_id(buf)
+    if rc != PTX_OK:
+        raise PtxError(rc, L.ptx_last_error(None).decode())
+    return buf.raw
 
 
 def _fp(a):
@@ -119,13 +134,16 @@ class Context:
     """One GPU, one scene, one progressive accumulation (ptx_ctx)."""
 
     def __init__(self, device=0):
+        """device: one HIP ordinal, or a list of them for one context over several GPUs (include/ptx.h ptx_create)."""
         self._lib = load_library()
-        ids = (C.c_int * 1)(int(device))
-        self._h = self._lib.ptx_create(ids, 1)
+        devs = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+        ids = (C.c_int * len(devs))(*devs)
+        self._h = self._lib.ptx_create(ids, len(devs))
         if not self._h:
             raise PtxError(PTX_ERR_HIP, self._lib.ptx_last_error(None).decode())
         self.params = None
-        self.device = int(device)
+        self.devices = devs
+        self.device = devs[0]
 
     def close(self):
         if getattr(self, "_h", None):
@@ -150,6 +168,8 @@ class Context:
 
     # ---- scene + parameters
     def upload_scene(self, s):
+        if hasattr(s, "validate"):
+            s.validate()          # dtype, contiguity and length of every array: the C side can only check index VALUES
         cs = CScene(s.T, s.N, s.L, _fp(s.coords), _fp(s.normals), _fp(s.colors), _fp(s.emissions), _ip(s.light_tri),
                     _fp(s.node_min), _fp(s.node_max), _ip(s.node_miss), _ip(s.node_first), _ip(s.node_count), _ip(s.inorder_tri))
         self._check(self._lib.ptx_upload_scene(self._h, C.byref(cs)))
@@ -188,6 +208,8 @@ class Context:
 
     # ---- read-back (row 0 = bottom row, like gl.readPixels)
     def _img(self, ch, dtype):
+        if self.params is None:
+            raise PtxError(PTX_ERR_STATE, "set_params first")
         return np.zeros((self.params.height, self.params.width, ch), dtype=dtype)
 
     def read_linear(self):
@@ -249,7 +271,22 @@ class Context:
     def reset_counters(self):
         self._check(self._lib.ptx_reset_counters(self._h))
 
-    # ---- multi-process reduction hooks
+    # ---- multi-GPU, one process per GPU (RCCL inside the library)
+    def comm_init(self, id128, rank, world):
+        self._check(self._lib.ptx_comm_init(self._h, C.c_char_p(bytes(id128)), int(rank), int(world)))
+
+    @property
+    def comm_world(self):
+        return self._lib.ptx_comm_world(self._h)
+
+    def allreduce(self, device_ptr=None):
+        """Sums accumulation + frame counts over the ranks (ptx_allreduce); in place when device_ptr is None.
+        Returns the total frame count."""
+        total = C.c_uint32(0)
+        self._check(self._lib.ptx_allreduce(self._h, C.c_void_p(int(device_ptr)) if device_ptr else None, C.byref(total)))
+        return int(total.value)
+
+    # ---- reduction hooks for a caller-side collective
     def accum_export_device(self, device_ptr):
         self._check(self._lib.ptx_accum_export_device(self._h, C.c_void_p(int(device_ptr))))
 

@@ -218,6 +218,16 @@ struct ptx_ctx {
     // options
     int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128, opt_compat = 0, opt_pool_chunk = 64;
 
+    // multi-GPU (DESIGN.md "Multi-GPU")
+    std::vector<ptx_ctx*> subs;                 // ptx_create with n_devices > 1: one single-device context per device id; this object only routes
+    bool same_device = false;                   // all subs on ONE device (rehearsal on a 1-GPU box): summed by k_sum_accums, no RCCL
+    std::vector<void*> group_comms;             // ncclComm_t per sub (ncclCommInitAll), created at the first reduction
+    bool total_valid = false;                   // subs[0]->d_total holds the sum of the subs' accumulations as they are now
+    float4* d_total = nullptr;                  // W*H float4: destination of the all-reduce (sub contexts; ptx_allreduce with d_dst == NULL stays in place)
+    void* comm = nullptr;                       // one process per GPU: ncclComm_t of ptx_comm_init
+    int comm_world = 0, comm_rank = -1;
+    unsigned long long* d_comm_cnt = nullptr;   // frames_done travels through the same communicator
+
     // counters + timing
     unsigned long long* d_counters = nullptr;
     uint32_t* d_task_counter = nullptr;       // pipeline 2: next undrawn (pixel, frame) task of the running launch
@@ -271,6 +281,24 @@ static int fail(ptx_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// ---- multi-device contexts route every entry point to their subs (definitions at the end of this file)
+static int multi_upload_scene(ptx_ctx*, const ptx_scene*);
+static int multi_set_params(ptx_ctx*, const ptx_params*);
+static int multi_set_option(ptx_ctx*, const char*, int64_t);
+static int multi_render_frames(ptx_ctx*, const int32_t*, uint32_t, uint32_t, bool noalloc);
+static int multi_for_all(ptx_ctx*, int (*fn)(ptx_ctx*));
+static int multi_frames_done(const ptx_ctx*);
+static int multi_read(ptx_ctx*, int kind, void* out, int a, int b);
+static int multi_write_sum(ptx_ctx*, const float*, uint32_t);
+static int multi_get_counters(ptx_ctx*, ptx_counters*);
+static int multi_accum_export(ptx_ctx*, void*);
+static int multi_accum_import(ptx_ctx*, const void*, uint32_t);
+static void multi_destroy(ptx_ctx*);
+static ptx_ctx* multi_create(const int* device_ids, int n_devices);
+static void comm_release(ptx_ctx*);
+#define PTX_MULTI(ctx, call) do { if ((ctx) && !(ctx)->subs.empty()) return (call); } while (0)
+enum { RD_LINEAR = 0, RD_SUM, RD_RGBA8, RD_COMPAT };
+
 extern "C" int ptx_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -282,10 +310,11 @@ extern "C" const char* ptx_last_error(const ptx_ctx* ctx) { return ctx ? ctx->er
 extern "C" void ptx_destroy(ptx_ctx* ctx);
 
 extern "C" ptx_ctx* ptx_create(const int* device_ids, int n_devices) {
-    if (!device_ids || n_devices != 1) {
-        g_create_error = "ptx_create: exactly one device per context (multi-GPU = one context per GPU)";
+    if (!device_ids || n_devices < 1 || n_devices > 64) {
+        g_create_error = "ptx_create: device_ids must list 1 .. 64 devices";
         return nullptr;
     }
+    if (n_devices > 1) return multi_create(device_ids, n_devices);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
@@ -332,6 +361,8 @@ static void free_params_buffers(ptx_ctx* ctx) {
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     for (int k = 0; k < 2; k++) { if (ctx->d_compat[k]) (void)hipFree(ctx->d_compat[k]); ctx->d_compat[k] = nullptr; }
     if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+    if (ctx->d_total) (void)hipFree(ctx->d_total);
+    ctx->d_total = nullptr;
     ctx->d_prim_t = nullptr; ctx->d_prim_tri = nullptr; ctx->d_accum = nullptr; ctx->d_fb = nullptr;
     ctx->fb_frames = 0;
     ctx->prim_valid = false;
@@ -351,8 +382,10 @@ static int ensure_stage(ptx_ctx* ctx, size_t bytes) {
 
 extern "C" void ptx_destroy(ptx_ctx* ctx) {
     if (!ctx) return;
+    if (!ctx->subs.empty()) { multi_destroy(ctx); return; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
     free_scene(ctx);
     free_params_buffers(ctx);
     if (ctx->d_ts) (void)hipFree(ctx->d_ts);
@@ -690,6 +723,7 @@ static void repack_nodes(std::vector<float4>& n) {
 
 extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_upload_scene(ctx, sc));
     if (!sc) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: scene is NULL");
     const uint32_t T = sc->T, N = sc->N, L = sc->L;
     if (T == 0 || N == 0) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: T and N must be > 0");
@@ -830,6 +864,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
 
 extern "C" int ptx_reset_accum(ptx_ctx* ctx) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_for_all(ctx, ptx_reset_accum));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_reset_accum: ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), ctx->stream));
@@ -841,6 +876,7 @@ extern "C" int ptx_reset_accum(ptx_ctx* ctx) {
 
 extern "C" int ptx_set_params(ptx_ctx* ctx, const ptx_params* p) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_set_params(ctx, p));
     if (!p) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: params is NULL");
     if (p->width == 0 || p->height == 0 || (uint64_t)p->width * p->height > (1ull << 26)) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: bad image size (width * height must be in 1 .. 2^26)");
     if (p->sample_count < 1) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: sample_count must be >= 1");
@@ -873,6 +909,7 @@ extern "C" int ptx_set_params(ptx_ctx* ctx, const ptx_params* p) {
 
 extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_set_option(ctx, key, value));
     const std::string k(key);
     if (k == "traversal" && value >= 0 && value <= 3) { ctx->opt_traversal = (int)value; ctx->prim_valid = false; }
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
@@ -1027,6 +1064,7 @@ static int render_batch(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf, uint32_
 
 extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_render_frames(ctx, timestamps, n_frames, first_frame_number, false));
     if (!timestamps && n_frames) return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames: timestamps is NULL");
     if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_render_frames: scene and params must be set first");
     if (n_frames == 0) return PTX_OK;
@@ -1058,9 +1096,15 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
                 HIP_TRY(ctx, hipMalloc(&ctx->d_compat[k], npix * sizeof(uchar4)));
                 HIP_TRY(ctx, hipMemsetAsync(ctx->d_compat[k], 0, npix * sizeof(uchar4), ctx->stream));
             }
-    // all timestamps of the call in ONE copy (pageable source: the runtime stages it before returning, so the caller's array
-    // is free to go); earlier batches of this stream that still read d_ts are ordered before it
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ts, timestamps, (size_t)n_frames * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    // the timestamps travel by value in kernel arguments, 64 per launch: no copy from pageable host memory, which would make
+    // the call wait for everything queued before it; the caller's array is free to go when this returns
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += PTX_SCRATCH_MAX_BATCH) {
+        const uint32_t nf = std::min<uint32_t>(PTX_SCRATCH_MAX_BATCH, n_frames - f0);
+        TsBlock tb = {};
+        std::memcpy(tb.v, timestamps + f0, nf * sizeof(int32_t));
+        hipLaunchKernelGGL(k_store_timestamps, dim3(1), dim3(64), 0, ctx->stream, tb, ctx->d_ts + f0, nf);
+    }
+    HIP_TRY(ctx, hipGetLastError());
     for (uint32_t f0 = 0; f0 < n_frames; f0 += (uint32_t)batch) {
         const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
         const RenderBufs rb = {ctx->d_fb, ctx->d_ts + f0, ctx->d_task_counter};
@@ -1074,6 +1118,7 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
 // ptx_render_frames.  All contexts on one GPU share that GPU's scratch: calls that overlap on one GPU race.
 extern "C" int ptx_render_frames_noalloc(ptx_ctx* ctx, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_render_frames(ctx, timestamps, n_frames, first_frame_number, true));
     if (!timestamps && n_frames) return fail(ctx, PTX_ERR_INVALID, "ptx_render_frames_noalloc: timestamps is NULL");
     if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_render_frames_noalloc: scene and params must be set first");
     if (!ctx->d_scratch) return fail(ctx, PTX_ERR_STATE, "ptx_render_frames_noalloc: no scratch on this device");
@@ -1105,13 +1150,17 @@ extern "C" int ptx_render_frames_noalloc(ptx_ctx* ctx, const int32_t* timestamps
 
 extern "C" int ptx_synchronize(ptx_ctx* ctx) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_for_all(ctx, ptx_synchronize));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     drain_events(ctx);
     return PTX_OK;
 }
 
-extern "C" int ptx_frames_done(const ptx_ctx* ctx) { return ctx ? (int)ctx->frames_done : PTX_ERR_INVALID; }
+extern "C" int ptx_frames_done(const ptx_ctx* ctx) {
+    if (ctx && !ctx->subs.empty()) return multi_frames_done(ctx);
+    return ctx ? (int)ctx->frames_done : PTX_ERR_INVALID;
+}
 
 static int read_accum(ptx_ctx* ctx, std::vector<float4>& h) {
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
@@ -1124,6 +1173,7 @@ static int read_accum(ptx_ctx* ctx, std::vector<float4>& h) {
 
 extern "C" int ptx_read_sum_f32(ptx_ctx* ctx, float* rgb) {
     if (!ctx || !rgb) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_read(ctx, RD_SUM, rgb, 0, 0));
     std::vector<float4> h;
     int rc = read_accum(ctx, h);
     if (rc) return rc;
@@ -1133,6 +1183,7 @@ extern "C" int ptx_read_sum_f32(ptx_ctx* ctx, float* rgb) {
 
 extern "C" int ptx_read_linear_f32(ptx_ctx* ctx, float* rgb) {
     if (!ctx || !rgb) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_read(ctx, RD_LINEAR, rgb, 0, 0));
     std::vector<float4> h;
     int rc = read_accum(ctx, h);
     if (rc) return rc;
@@ -1143,6 +1194,7 @@ extern "C" int ptx_read_linear_f32(ptx_ctx* ctx, float* rgb) {
 
 extern "C" int ptx_read_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int flip_y) {
     if (!ctx || !out) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_read(ctx, RD_RGBA8, out, apply_gamma, flip_y));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
@@ -1161,6 +1213,7 @@ extern "C" int ptx_read_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int f
 
 extern "C" int ptx_read_compat_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int flip_y) {
     if (!ctx || !out) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, fail(ctx, PTX_ERR_STATE, "ptx_read_compat_rgba8: the 8-bit progressive blend is sequential over frames; it needs a single-device context"));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
     if (!ctx->d_compat[0]) return fail(ctx, PTX_ERR_STATE, "ptx_read_compat_rgba8: no frame was rendered with option compat_rgba8 = 1");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1181,6 +1234,7 @@ extern "C" int ptx_read_compat_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma
 // Checkpoint restore: the accumulation becomes `rgb` (W*H*3, as ptx_read_sum_f32 wrote it) with frames_done frames in it.
 extern "C" int ptx_write_sum_f32(ptx_ctx* ctx, const float* rgb, uint32_t frames_done) {
     if (!ctx || !rgb) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_write_sum(ctx, rgb, frames_done));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_write_sum_f32: ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
@@ -1194,6 +1248,7 @@ extern "C" int ptx_write_sum_f32(ptx_ctx* ctx, const float* rgb, uint32_t frames
 
 extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, uint32_t n, float* t, int32_t* tri_id) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, ptx_trace_closest(ctx->subs[0], o, d, n, t, tri_id));
     if (!ctx->have_scene) return fail(ctx, PTX_ERR_STATE, "ptx_trace_closest: ptx_upload_scene first");
     if (n == 0) return PTX_OK;
     if (!o || !d || !t || !tri_id) return fail(ctx, PTX_ERR_INVALID, "ptx_trace_closest: NULL array");
@@ -1229,6 +1284,7 @@ extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, u
 
 extern "C" int ptx_primary_hits(ptx_ctx* ctx, int32_t* tri_id, float* t) {
     if (!ctx || !tri_id || !t) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, ptx_primary_hits(ctx->subs[0], tri_id, t));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_primary(ctx, nullptr);
     if (rc) return rc;
@@ -1241,6 +1297,7 @@ extern "C" int ptx_primary_hits(ptx_ctx* ctx, int32_t* tri_id, float* t) {
 
 extern "C" int ptx_primary_dirs(ptx_ctx* ctx, float* dirs) {
     if (!ctx || !dirs) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, ptx_primary_dirs(ctx->subs[0], dirs));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "scene and params must be set first");
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
@@ -1259,6 +1316,7 @@ extern "C" int ptx_primary_dirs(ptx_ctx* ctx, float* dirs) {
 
 extern "C" int ptx_get_counters(ptx_ctx* ctx, ptx_counters* out) {
     if (!ctx || !out) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_get_counters(ctx, out));
     int rc = ptx_synchronize(ctx);
     if (rc) return rc;
     unsigned long long h[CNT_NUM];
@@ -1274,6 +1332,7 @@ extern "C" int ptx_get_counters(ptx_ctx* ctx, ptx_counters* out) {
 
 extern "C" int ptx_reset_counters(ptx_ctx* ctx) {
     if (!ctx) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_for_all(ctx, ptx_reset_counters));
     int rc = ptx_synchronize(ctx);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long)));
@@ -1284,6 +1343,7 @@ extern "C" int ptx_reset_counters(ptx_ctx* ctx) {
 
 extern "C" int ptx_accum_export_device(ptx_ctx* ctx, void* d_dst) {
     if (!ctx || !d_dst) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_accum_export(ctx, d_dst));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(d_dst, ctx->d_accum, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1294,10 +1354,379 @@ extern "C" int ptx_accum_export_device(ptx_ctx* ctx, void* d_dst) {
 
 extern "C" int ptx_accum_import_device(ptx_ctx* ctx, const void* d_src, uint32_t frames_done) {
     if (!ctx || !d_src) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, multi_accum_import(ctx, d_src, frames_done));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, d_src, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->frames_done = frames_done;
+    return PTX_OK;
+}
+
+extern "C" int ptx_get_size(const ptx_ctx* ctx, uint32_t* width, uint32_t* height) {
+    if (!ctx || !width || !height) return PTX_ERR_INVALID;
+    const ptx_ctx* c = ctx->subs.empty() ? ctx : ctx->subs[0];
+    if (!c->have_params) return PTX_ERR_STATE;
+    *width = c->P.W; *height = c->P.H;
+    return PTX_OK;
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU
+// Every (pixel, frame) is independent, so G GPUs render frames {g, g + G, ...} of the timestamp list over the full image
+// into their own float accumulation buffers, and ONE all-reduce (RCCL over xGMI) of W*H*4 floats sums them.  Two shapes:
+//   * one process, G devices:   ptx_create(device_ids, G) -- a routing context over G single-device contexts; the
+//     communicators come from ncclCommInitAll, the all-reduce runs grouped on the subs' streams when a read-back needs the
+//     sum (the Node host: the reference is one single-threaded JS process, main.js:391-438);
+//   * one process per GPU:      ptx_comm_unique_id / ptx_comm_init / ptx_allreduce on ordinary single-device contexts
+//     (bench.py under torch.distributed.run; the id travels over whatever channel the caller has).
+// librccl is loaded on first use (dlopen), so single-GPU users never map it; an already mapped copy (torch bundles one)
+// is preferred, so that the process keeps ONE RCCL and ONE HIP runtime.
+#include <dlfcn.h>
+
+namespace {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;       // NCCL_UNIQUE_ID_BYTES (rccl.h:40-43)
+enum { NCCL_SUM = 0, NCCL_UINT64 = 5, NCCL_FLOAT32 = 7 };  // ncclRedOp_t / ncclDataType_t values of rccl.h:448-466
+struct RcclApi {
+    void* lib = nullptr;
+    std::string path;
+    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+std::string g_comm_error;
+
+const RcclApi* rccl_api(std::string* err) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.lib) return &g_rccl;
+    void* h = nullptr;
+    std::string tried;
+    const char* env = getenv("PTX_RCCL_LIB");
+    if (env && *env) { h = dlopen(env, RTLD_NOW | RTLD_GLOBAL); g_rccl.path = env; if (!h) tried += std::string(env) + ": " + dlerror() + "; "; }
+    // a copy that is already mapped (torch's librccl.so has no SONAME, ROCm's is librccl.so.1)
+    for (const char* name : {"librccl.so", "librccl.so.1"})
+        if (!h && (h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) g_rccl.path = std::string(name) + " (already mapped)";
+    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"})
+        if (!h) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); g_rccl.path = name; if (!h) tried += std::string(name) + ": " + dlerror() + "; "; }
+    if (!h) { *err = "cannot load librccl (" + tried + ")"; return nullptr; }
+    RcclApi a;
+    a.lib = h; a.path = g_rccl.path;
+#define PTX_SYM(field, name) if (!(*(void**)(&a.field) = dlsym(h, name))) { *err = std::string("librccl lacks ") + name; return nullptr; }
+    PTX_SYM(GetUniqueId, "ncclGetUniqueId") PTX_SYM(CommInitRank, "ncclCommInitRank") PTX_SYM(CommInitAll, "ncclCommInitAll")
+    PTX_SYM(CommDestroy, "ncclCommDestroy") PTX_SYM(CommCount, "ncclCommCount") PTX_SYM(AllReduce, "ncclAllReduce")
+    PTX_SYM(GroupStart, "ncclGroupStart") PTX_SYM(GroupEnd, "ncclGroupEnd") PTX_SYM(GetErrorString, "ncclGetErrorString")
+#undef PTX_SYM
+    g_rccl = a;
+    return &g_rccl;
+}
+}  // namespace
+
+#define NCCL_TRY(ctx, api, expr)                                                                         \
+    do {                                                                                                 \
+        const int r_ = (expr);                                                                           \
+        if (r_ != 0) return fail((ctx), PTX_ERR_HIP, std::string(#expr) + ": " + (api)->GetErrorString(r_)); \
+    } while (0)
+
+// dst[p] = ((src[0][p] + src[1][p]) + src[2][p]) + ...  -- the all-reduce of contexts that share ONE device (fixed order)
+struct SumSrcs { const float4* p[64]; int n; };
+__global__ __launch_bounds__(256) void k_sum_accums(float4* __restrict__ dst, SumSrcs srcs, uint32_t npix) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= npix) return;
+    float4 a = srcs.p[0][i];
+    for (int g = 1; g < srcs.n; g++) {
+        const float4 v = srcs.p[g][i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    dst[i] = a;
+}
+
+static void comm_release(ptx_ctx* ctx) {
+    if (ctx->comm) {
+        std::string err;
+        const RcclApi* api = rccl_api(&err);
+        if (api) (void)api->CommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->comm_world = 0; ctx->comm_rank = -1;
+    if (ctx->d_comm_cnt) { (void)hipFree(ctx->d_comm_cnt); ctx->d_comm_cnt = nullptr; }
+}
+
+// ---- one process per GPU
+extern "C" int ptx_comm_unique_id(void* id128) {
+    if (!id128) return PTX_ERR_INVALID;
+    const RcclApi* api = rccl_api(&g_comm_error);
+    if (!api) { g_create_error = "ptx_comm_unique_id: " + g_comm_error; return PTX_ERR_HIP; }
+    ncclUniqueId id;
+    const int r = api->GetUniqueId(&id);
+    if (r != 0) { g_create_error = std::string("ncclGetUniqueId: ") + api->GetErrorString(r); return PTX_ERR_HIP; }
+    std::memcpy(id128, id.internal, sizeof id.internal);
+    return PTX_OK;
+}
+
+extern "C" int ptx_comm_init(ptx_ctx* ctx, const void* id128, int rank, int world) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!ctx->subs.empty()) return fail(ctx, PTX_ERR_STATE, "ptx_comm_init: a multi-device context reduces by itself; communicators are for one context per process");
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, PTX_ERR_INVALID, "ptx_comm_init: need an id and 0 <= rank < world");
+    std::string err;
+    const RcclApi* api = rccl_api(&err);
+    if (!api) return fail(ctx, PTX_ERR_HIP, "ptx_comm_init: " + err);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    comm_release(ctx);
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, sizeof id.internal);
+    ncclComm_t comm = nullptr;
+    NCCL_TRY(ctx, api, api->CommInitRank(&comm, world, id, rank));
+    ctx->comm = comm; ctx->comm_world = world; ctx->comm_rank = rank;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_comm_cnt, sizeof(unsigned long long)));
+    return PTX_OK;
+}
+
+extern "C" int ptx_comm_world(const ptx_ctx* ctx) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!ctx->subs.empty()) return (int)ctx->subs.size();
+    if (!ctx->comm) return 0;
+    std::string err;
+    const RcclApi* api = rccl_api(&err);
+    int n = 0;
+    if (!api || api->CommCount((ncclComm_t)ctx->comm, &n) != 0) return PTX_ERR_HIP;
+    return n;                                           // what RCCL itself reports, not what the caller passed in
+}
+
+// Sums the accumulation buffers (W*H*4 f32) and the frame counts of all ranks with one grouped ncclAllReduce pair on the
+// context's stream.  d_dst == NULL: in place -- afterwards every rank's accumulation IS the total and frames_done the total
+// count (all-reduce once, at the end of the job).  d_dst != NULL: the total goes to that device buffer and the rank's own
+// accumulation stays as it is (progress previews).  Blocks until done.
+extern "C" int ptx_allreduce(ptx_ctx* ctx, void* d_dst, uint32_t* frames_total) {
+    if (!ctx) return PTX_ERR_INVALID;
+    if (!ctx->subs.empty()) return fail(ctx, PTX_ERR_STATE, "ptx_allreduce: a multi-device context reduces by itself when it is read");
+    if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_allreduce: ptx_set_params first");
+    if (!ctx->comm) return fail(ctx, PTX_ERR_STATE, "ptx_allreduce: ptx_comm_init first");
+    std::string err;
+    const RcclApi* api = rccl_api(&err);
+    if (!api) return fail(ctx, PTX_ERR_HIP, "ptx_allreduce: " + err);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t count = (size_t)ctx->P.W * ctx->P.H * 4;
+    const unsigned long long mine = ctx->frames_done;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_comm_cnt, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    NCCL_TRY(ctx, api, api->GroupStart());
+    const int r1 = api->AllReduce(ctx->d_accum, d_dst ? d_dst : (void*)ctx->d_accum, count, NCCL_FLOAT32, NCCL_SUM, (ncclComm_t)ctx->comm, ctx->stream);
+    const int r2 = api->AllReduce(ctx->d_comm_cnt, ctx->d_comm_cnt, 1, NCCL_UINT64, NCCL_SUM, (ncclComm_t)ctx->comm, ctx->stream);
+    const int r3 = api->GroupEnd();
+    if (r1 || r2 || r3) return fail(ctx, PTX_ERR_HIP, std::string("ncclAllReduce: ") + api->GetErrorString(r1 ? r1 : (r2 ? r2 : r3)));
+    unsigned long long total = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_comm_cnt, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    drain_events(ctx);
+    if (!d_dst) ctx->frames_done = (uint32_t)total;
+    if (frames_total) *frames_total = (uint32_t)total;
+    return PTX_OK;
+}
+
+// ---- one process, G devices: the routing context
+static int sub_fail(ptx_ctx* m, const ptx_ctx* sub, int rc) { m->err = sub->err; return rc; }
+
+static ptx_ctx* multi_create(const int* device_ids, int n_devices) {
+    bool all_same = true, all_distinct = true;
+    for (int a = 0; a < n_devices; a++)
+        for (int b = a + 1; b < n_devices; b++) {
+            if (device_ids[a] == device_ids[b]) all_distinct = false; else all_same = false;
+        }
+    if (!all_same && !all_distinct) {
+        g_create_error = "ptx_create: device_ids must be all distinct (RCCL all-reduce) or all the same device (one-GPU rehearsal)";
+        return nullptr;
+    }
+    ptx_ctx* m = new ptx_ctx();
+    m->device = device_ids[0];
+    m->same_device = all_same;
+    for (int g = 0; g < n_devices; g++) {
+        ptx_ctx* sub = ptx_create(device_ids + g, 1);
+        if (!sub) { multi_destroy(m); return nullptr; }          // g_create_error is set
+        m->subs.push_back(sub);
+    }
+    return m;
+}
+
+static void multi_destroy(ptx_ctx* m) {
+    if (!m->group_comms.empty()) {
+        std::string err;
+        const RcclApi* api = rccl_api(&err);
+        for (void* c : m->group_comms) if (api && c) (void)api->CommDestroy((ncclComm_t)c);
+    }
+    std::vector<ptx_ctx*> subs;
+    subs.swap(m->subs);                                       // ptx_destroy(sub) must not route
+    for (ptx_ctx* s : subs) ptx_destroy(s);
+    delete m;
+}
+
+static int multi_for_all(ptx_ctx* m, int (*fn)(ptx_ctx*)) {
+    m->total_valid = false;
+    for (ptx_ctx* s : m->subs) { const int rc = fn(s); if (rc) return sub_fail(m, s, rc); }
+    return PTX_OK;
+}
+static int multi_upload_scene(ptx_ctx* m, const ptx_scene* sc) {
+    for (ptx_ctx* s : m->subs) { const int rc = ptx_upload_scene(s, sc); if (rc) return sub_fail(m, s, rc); }
+    return PTX_OK;
+}
+static int multi_set_params(ptx_ctx* m, const ptx_params* p) {
+    m->total_valid = false;
+    for (ptx_ctx* s : m->subs) { const int rc = ptx_set_params(s, p); if (rc) return sub_fail(m, s, rc); }
+    return PTX_OK;
+}
+static int multi_set_option(ptx_ctx* m, const char* key, int64_t value) {
+    if (key && std::string(key) == "compat_rgba8" && value != 0)
+        return fail(m, PTX_ERR_INVALID, "ptx_set_option: compat_rgba8 blends frame after frame through one 8-bit target; it needs a single-device context");
+    for (ptx_ctx* s : m->subs) { const int rc = ptx_set_option(s, key, value); if (rc) return sub_fail(m, s, rc); }
+    return PTX_OK;
+}
+
+// frames {g, g + G, ...} of this call go to device g; every sub call only queues work, so the devices render concurrently
+static int multi_render_frames(ptx_ctx* m, const int32_t* timestamps, uint32_t n_frames, uint32_t first_frame_number, bool noalloc) {
+    if (!timestamps && n_frames) return fail(m, PTX_ERR_INVALID, "ptx_render_frames: timestamps is NULL");
+    const uint32_t G = (uint32_t)m->subs.size();
+    m->total_valid = false;
+    std::vector<int32_t> mine;
+    for (uint32_t g = 0; g < G; g++) {
+        mine.clear();
+        for (uint32_t f = g; f < n_frames; f += G) mine.push_back(timestamps[f]);
+        if (mine.empty()) continue;
+        ptx_ctx* s = m->subs[g];
+        const int rc = noalloc ? ptx_render_frames_noalloc(s, mine.data(), (uint32_t)mine.size(), first_frame_number + g)
+                               : ptx_render_frames(s, mine.data(), (uint32_t)mine.size(), first_frame_number + g);
+        if (rc) return sub_fail(m, s, rc);
+        // the subs of a one-GPU rehearsal share that GPU's static scratch: their no-alloc launches must not overlap
+        if (noalloc && m->same_device) { const int rs = ptx_synchronize(s); if (rs) return sub_fail(m, s, rs); }
+    }
+    return PTX_OK;
+}
+
+static int multi_frames_done(const ptx_ctx* m) {
+    int n = 0;
+    for (const ptx_ctx* s : m->subs) n += (int)s->frames_done;
+    return n;
+}
+
+// The sum of the subs' accumulations into subs[0]->d_total (every sub's d_total with RCCL): one grouped ncclAllReduce over
+// the communicators of ncclCommInitAll, or k_sum_accums when the subs share one device.
+static int multi_reduce(ptx_ctx* m) {
+    if (m->total_valid) return PTX_OK;
+    const size_t G = m->subs.size();
+    ptx_ctx* s0 = m->subs[0];
+    if (!s0->have_params) return fail(m, PTX_ERR_STATE, "ptx_set_params first");
+    const size_t npix = (size_t)s0->P.W * s0->P.H;
+    for (ptx_ctx* s : m->subs) {
+        if (s->d_total) continue;
+        HIP_TRY(m, hipSetDevice(s->device));
+        HIP_TRY(m, hipMalloc(&s->d_total, npix * sizeof(float4)));
+    }
+    if (m->same_device) {
+        SumSrcs srcs = {};
+        srcs.n = (int)G;
+        for (size_t g = 0; g < G; g++) srcs.p[g] = m->subs[g]->d_accum;
+        HIP_TRY(m, hipSetDevice(s0->device));
+        for (size_t g = 1; g < G; g++) HIP_TRY(m, hipStreamSynchronize(m->subs[g]->stream));    // their frames are in their buffers
+        hipLaunchKernelGGL(k_sum_accums, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, s0->stream, s0->d_total, srcs, (uint32_t)npix);
+        HIP_TRY(m, hipGetLastError());
+        HIP_TRY(m, hipStreamSynchronize(s0->stream));
+    } else {
+        std::string err;
+        const RcclApi* api = rccl_api(&err);
+        if (!api) return fail(m, PTX_ERR_HIP, "multi-GPU reduction: " + err);
+        if (m->group_comms.empty()) {
+            std::vector<int> devs;
+            for (ptx_ctx* s : m->subs) devs.push_back(s->device);
+            std::vector<ncclComm_t> comms(G, nullptr);
+            NCCL_TRY(m, api, api->CommInitAll(comms.data(), (int)G, devs.data()));
+            for (ncclComm_t c : comms) m->group_comms.push_back(c);
+        }
+        NCCL_TRY(m, api, api->GroupStart());
+        int bad = 0;
+        for (size_t g = 0; g < G && !bad; g++) {
+            ptx_ctx* s = m->subs[g];
+            if (hipSetDevice(s->device) != hipSuccess) { bad = -1; break; }
+            bad = api->AllReduce(s->d_accum, s->d_total, npix * 4, NCCL_FLOAT32, NCCL_SUM, (ncclComm_t)m->group_comms[g], s->stream);
+        }
+        const int end = api->GroupEnd();
+        if (bad || end) return fail(m, PTX_ERR_HIP, std::string("ncclAllReduce (grouped): ") + (bad > 0 ? api->GetErrorString(bad) : (end ? api->GetErrorString(end) : "hipSetDevice failed")));
+        for (ptx_ctx* s : m->subs) {
+            HIP_TRY(m, hipSetDevice(s->device));
+            HIP_TRY(m, hipStreamSynchronize(s->stream));
+        }
+    }
+    for (ptx_ctx* s : m->subs) drain_events(s);
+    m->total_valid = true;
+    return PTX_OK;
+}
+
+// read-backs see the total: subs[0] reads with its accumulation pointer and frame count swapped for the reduced ones
+static int multi_read(ptx_ctx* m, int kind, void* out, int a, int b) {
+    if (!out) return PTX_ERR_INVALID;
+    int rc = multi_reduce(m);
+    if (rc) return rc;
+    ptx_ctx* s0 = m->subs[0];
+    const uint32_t own_frames = s0->frames_done;
+    std::swap(s0->d_accum, s0->d_total);
+    s0->frames_done = (uint32_t)multi_frames_done(m);
+    switch (kind) {
+        case RD_LINEAR: rc = ptx_read_linear_f32(s0, (float*)out); break;
+        case RD_SUM: rc = ptx_read_sum_f32(s0, (float*)out); break;
+        default: rc = ptx_read_rgba8(s0, (uint8_t*)out, a, b); break;
+    }
+    std::swap(s0->d_accum, s0->d_total);
+    s0->frames_done = own_frames;
+    return rc ? sub_fail(m, s0, rc) : PTX_OK;
+}
+
+static int multi_write_sum(ptx_ctx* m, const float* rgb, uint32_t frames_done) {    // the checkpoint goes to device 0, the others start empty
+    if (!rgb) return PTX_ERR_INVALID;
+    m->total_valid = false;
+    for (size_t g = 0; g < m->subs.size(); g++) {
+        ptx_ctx* s = m->subs[g];
+        const int rc = g == 0 ? ptx_write_sum_f32(s, rgb, frames_done) : ptx_reset_accum(s);
+        if (rc) return sub_fail(m, s, rc);
+    }
+    return PTX_OK;
+}
+
+static int multi_get_counters(ptx_ctx* m, ptx_counters* out) {
+    if (!out) return PTX_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    for (ptx_ctx* s : m->subs) {
+        ptx_counters c;
+        const int rc = ptx_get_counters(s, &c);
+        if (rc) return sub_fail(m, s, rc);
+        out->samples += c.samples; out->rays += c.rays; out->rays_traced += c.rays_traced; out->node_visits += c.node_visits;
+        out->tri_tests += c.tri_tests; out->ray_hits += c.ray_hits; out->light_attempts += c.light_attempts; out->pixel_frames += c.pixel_frames;
+        out->kernel_launches += c.kernel_launches;
+        out->kernel_ms = std::max(out->kernel_ms, c.kernel_ms);       // the devices run side by side: the busiest one's time
+        for (int k = 0; k < 12; k++) out->diag[k] += c.diag[k];
+    }
+    return PTX_OK;
+}
+
+static int multi_accum_export(ptx_ctx* m, void* d_dst) {               // the reduced total, from device subs[0]
+    if (!d_dst) return PTX_ERR_INVALID;
+    int rc = multi_reduce(m);
+    if (rc) return rc;
+    ptx_ctx* s0 = m->subs[0];
+    HIP_TRY(m, hipSetDevice(s0->device));
+    HIP_TRY(m, hipMemcpy(d_dst, s0->d_total, (size_t)s0->P.W * s0->P.H * sizeof(float4), hipMemcpyDeviceToDevice));
+    return PTX_OK;
+}
+static int multi_accum_import(ptx_ctx* m, const void* d_src, uint32_t frames_done) {
+    if (!d_src) return PTX_ERR_INVALID;
+    m->total_valid = false;
+    for (size_t g = 0; g < m->subs.size(); g++) {
+        ptx_ctx* s = m->subs[g];
+        const int rc = g == 0 ? ptx_accum_import_device(s, d_src, frames_done) : ptx_reset_accum(s);
+        if (rc) return sub_fail(m, s, rc);
+    }
     return PTX_OK;
 }

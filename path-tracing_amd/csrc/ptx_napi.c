@@ -5,7 +5,9 @@
  * talks to WebGL (uploadTexture / gl.uniform* / gl.drawArrays / gl.readPixels, main.js:272-355,459).
  * It only converts JS values <-> plain pointers and sizes: typed arrays are validated against T/N/L, every
  * non-zero ptx_status becomes a JS Error carrying ptx_last_error, results come back in addon-allocated
- * ArrayBuffers.  Synchronous, main-thread only (the reference host is single-threaded JS).
+ * ArrayBuffers whose size comes from the context itself (ptx_get_size), never from the caller.  One context, one
+ * thread: while a renderFramesAsync job runs on the libuv pool the handle is marked busy (every other call on it
+ * throws, destroy included) and a reference keeps it alive until the job has settled.
  *
  * Build: cc -shared -fPIC -I/usr/include/node ptx_napi.c -o ptx_napi.node -L. -lptx_hip -Wl,-rpath,'$ORIGIN'
  */
@@ -41,13 +43,36 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
     return 1;
 }
 
-static ptx_ctx *get_ctx(napi_env env, napi_value v) {
+typedef struct slot {
+    ptx_ctx *ctx;
+    int busy; /* a renderFramesAsync job owns the context until it settles */
+} slot;
+
+static slot *get_slot(napi_env env, napi_value v) {
     void *p = NULL;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((slot *)p)->ctx) {
         napi_throw_type_error(env, NULL, "ptx_napi: not a context handle (or already destroyed)");
         return NULL;
     }
-    return *(ptx_ctx **)p;
+    if (((slot *)p)->busy) {
+        napi_throw_error(env, NULL, "ptx_napi: the context is busy with a renderFramesAsync job; await its promise first");
+        return NULL;
+    }
+    return (slot *)p;
+}
+
+static ptx_ctx *get_ctx(napi_env env, napi_value v) {
+    slot *s = get_slot(env, v);
+    return s ? s->ctx : NULL;
+}
+
+/* size of every read-back buffer: what the context was last given, not what the caller believes */
+static int get_size(napi_env env, ptx_ctx *ctx, uint32_t *w, uint32_t *h) {
+    if (ptx_get_size(ctx, w, h) != PTX_OK) {
+        napi_throw_error(env, NULL, "ptx_napi: setParams first");
+        return 0;
+    }
+    return 1;
 }
 
 /* typed array of the given type with exactly `want` elements (want = SIZE_MAX: any length) */
@@ -123,9 +148,9 @@ static napi_value make_typed(napi_env env, napi_typedarray_type type, size_t n, 
 
 static void finalize_ctx(napi_env env, void *data, void *hint) {
     (void)env; (void)hint;
-    ptx_ctx **slot = (ptx_ctx **)data;
-    if (*slot) ptx_destroy(*slot);
-    free(slot);
+    slot *s = (slot *)data;
+    if (s->ctx) ptx_destroy(s->ctx);
+    free(s);
 }
 
 static napi_value DeviceCount(napi_env env, napi_callback_info info) {
@@ -136,15 +161,23 @@ static napi_value DeviceCount(napi_env env, napi_callback_info info) {
 }
 
 static napi_value Create(napi_env env, napi_callback_info info) {
-    napi_value argv[1], ext;
-    int32_t dev = 0;
+    /* create(device) or create([device, ...]): one context over one or several GPUs (ptx_create) */
+    napi_value argv[1], ext, e;
+    int32_t devs[64];
+    uint32_t n = 1;
+    bool is_array = false;
     if (!get_args(env, info, 1, argv)) return NULL;
-    if (napi_get_value_int32(env, argv[0], &dev) != napi_ok) { napi_throw_type_error(env, NULL, "ptx_napi: device must be an integer"); return NULL; }
-    ptx_ctx *ctx = ptx_create(&dev, 1);
+    if (napi_is_array(env, argv[0], &is_array) == napi_ok && is_array) {
+        if (napi_get_array_length(env, argv[0], &n) != napi_ok || n < 1 || n > 64) { napi_throw_range_error(env, NULL, "ptx_napi: 1 .. 64 devices"); return NULL; }
+        for (uint32_t i = 0; i < n; i++)
+            if (napi_get_element(env, argv[0], i, &e) != napi_ok || napi_get_value_int32(env, e, &devs[i]) != napi_ok) { napi_throw_type_error(env, NULL, "ptx_napi: devices must be integers"); return NULL; }
+    } else if (napi_get_value_int32(env, argv[0], &devs[0]) != napi_ok) { napi_throw_type_error(env, NULL, "ptx_napi: device must be an integer or an array of integers"); return NULL; }
+    ptx_ctx *ctx = ptx_create(devs, (int)n);
     if (!ctx) return throw_ptx(env, NULL, PTX_ERR_HIP);
-    ptx_ctx **slot = (ptx_ctx **)malloc(sizeof *slot);
-    *slot = ctx;
-    NAPI_OK(env, napi_create_external(env, slot, finalize_ctx, NULL, &ext));
+    slot *s = (slot *)calloc(1, sizeof *s);
+    if (!s) { ptx_destroy(ctx); napi_throw_error(env, NULL, "ptx_napi: out of memory"); return NULL; }
+    s->ctx = ctx;
+    if (napi_create_external(env, s, finalize_ctx, NULL, &ext) != napi_ok) { ptx_destroy(ctx); free(s); napi_throw_error(env, NULL, "ptx_napi: cannot create the handle"); return NULL; }
     return ext;
 }
 
@@ -152,9 +185,10 @@ static napi_value Destroy(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     void *p = NULL;
     if (!get_args(env, info, 1, argv)) return NULL;
-    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && *(ptx_ctx **)p) {
-        ptx_destroy(*(ptx_ctx **)p);
-        *(ptx_ctx **)p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && ((slot *)p)->ctx) {
+        if (((slot *)p)->busy) { napi_throw_error(env, NULL, "ptx_napi: destroy() while a renderFramesAsync job runs; await its promise first"); return NULL; }
+        ptx_destroy(((slot *)p)->ctx);
+        ((slot *)p)->ctx = NULL;
     }
     return NULL;
 }
@@ -241,6 +275,8 @@ static napi_value RenderFrames(napi_env env, napi_callback_info info) {
 typedef struct render_job {
     napi_async_work work;
     napi_deferred deferred;
+    napi_ref handle_ref; /* keeps the external handle (and with it the context) alive while the worker runs */
+    slot *owner;
     ptx_ctx *ctx;
     int32_t *ts;
     uint32_t n, first;
@@ -268,6 +304,8 @@ static void render_complete(napi_env env, napi_status status, void *data) {
         napi_get_undefined(env, &v);
         napi_resolve_deferred(env, j->deferred, v);
     }
+    j->owner->busy = 0;
+    napi_delete_reference(env, j->handle_ref);
     napi_delete_async_work(env, j->work);
     free(j->ts);
     free(j);
@@ -278,8 +316,9 @@ static napi_value RenderFramesAsync(napi_env env, napi_callback_info info) {
     size_t n = 0;
     uint32_t first = 0;
     if (!get_args(env, info, 3, argv)) return NULL;
-    ptx_ctx *ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
+    slot *owner = get_slot(env, argv[0]);
+    if (!owner) return NULL;
+    ptx_ctx *ctx = owner->ctx;
     const int32_t *ts = (const int32_t *)get_typed(env, argv[1], napi_int32_array, SIZE_MAX, &n, "timestamps");
     if (!ts) return NULL;
     if (napi_get_value_uint32(env, argv[2], &first) != napi_ok) { napi_throw_type_error(env, NULL, "ptx_napi: firstFrameNumber must be an integer"); return NULL; }
@@ -287,11 +326,15 @@ static napi_value RenderFramesAsync(napi_env env, napi_callback_info info) {
     if (j) j->ts = (int32_t *)malloc((n ? n : 1) * sizeof(int32_t));
     if (!j || !j->ts) { free(j); napi_throw_error(env, NULL, "ptx_napi: out of memory"); return NULL; }
     memcpy(j->ts, ts, n * sizeof(int32_t));     /* the typed array may be collected before the worker runs */
-    j->ctx = ctx; j->n = (uint32_t)n; j->first = first;
+    j->ctx = ctx; j->owner = owner; j->n = (uint32_t)n; j->first = first;
+    if (napi_create_reference(env, argv[0], 1, &j->handle_ref) != napi_ok) { free(j->ts); free(j); napi_throw_error(env, NULL, "ptx_napi: cannot reference the handle"); return NULL; }
+    owner->busy = 1;
     if (napi_create_promise(env, &j->deferred, &promise) != napi_ok ||
         napi_create_string_utf8(env, "ptx_render_frames", NAPI_AUTO_LENGTH, &name) != napi_ok ||
         napi_create_async_work(env, NULL, name, render_execute, render_complete, j, &j->work) != napi_ok ||
         napi_queue_async_work(env, j->work) != napi_ok) {
+        owner->busy = 0;
+        napi_delete_reference(env, j->handle_ref);
         free(j->ts); free(j);
         napi_throw_error(env, NULL, "ptx_napi: cannot queue the render job");
         return NULL;
@@ -319,16 +362,12 @@ static napi_value FramesDone(napi_env env, napi_callback_info info) {
 }
 
 static napi_value read_f32(napi_env env, napi_callback_info info, int (*fn)(ptx_ctx *, float *)) {
-    napi_value argv[3];
+    napi_value argv[1];
     uint32_t w = 0, h = 0;
     void *data = NULL;
-    if (!get_args(env, info, 3, argv)) return NULL;
+    if (!get_args(env, info, 1, argv)) return NULL;
     ptx_ctx *ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
-    if (napi_get_value_uint32(env, argv[1], &w) != napi_ok || napi_get_value_uint32(env, argv[2], &h) != napi_ok) {
-        napi_throw_type_error(env, NULL, "ptx_napi: read(handle, width, height)");
-        return NULL;
-    }
+    if (!ctx || !get_size(env, ctx, &w, &h)) return NULL;
     napi_value ta = make_typed(env, napi_float32_array, (size_t)w * h * 3, 4, &data);
     if (!ta) return NULL;
     int rc = fn(ctx, (float *)data);
@@ -339,15 +378,14 @@ static napi_value ReadLinear(napi_env env, napi_callback_info info) { return rea
 static napi_value ReadSum(napi_env env, napi_callback_info info) { return read_f32(env, info, ptx_read_sum_f32); }
 
 static napi_value read_u8(napi_env env, napi_callback_info info, int (*fn)(ptx_ctx *, uint8_t *, int, int), const char *usage) {
-    napi_value argv[5];
+    napi_value argv[3];
     uint32_t w = 0, h = 0;
     bool gamma = true, flip = true;
     void *data = NULL;
-    if (!get_args(env, info, 5, argv)) return NULL;
+    if (!get_args(env, info, 3, argv)) return NULL;
     ptx_ctx *ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
-    if (napi_get_value_uint32(env, argv[1], &w) != napi_ok || napi_get_value_uint32(env, argv[2], &h) != napi_ok ||
-        napi_get_value_bool(env, argv[3], &gamma) != napi_ok || napi_get_value_bool(env, argv[4], &flip) != napi_ok) {
+    if (!ctx || !get_size(env, ctx, &w, &h)) return NULL;
+    if (napi_get_value_bool(env, argv[1], &gamma) != napi_ok || napi_get_value_bool(env, argv[2], &flip) != napi_ok) {
         napi_throw_type_error(env, NULL, usage);
         return NULL;
     }
@@ -358,25 +396,24 @@ static napi_value read_u8(napi_env env, napi_callback_info info, int (*fn)(ptx_c
     return ta;
 }
 static napi_value ReadRgba8(napi_env env, napi_callback_info info) {
-    return read_u8(env, info, ptx_read_rgba8, "ptx_napi: readRgba8(handle, width, height, gamma:boolean, flipY:boolean)");
+    return read_u8(env, info, ptx_read_rgba8, "ptx_napi: readRgba8(handle, gamma:boolean, flipY:boolean)");
 }
 static napi_value ReadCompatRgba8(napi_env env, napi_callback_info info) {
-    return read_u8(env, info, ptx_read_compat_rgba8, "ptx_napi: readCompatRgba8(handle, width, height, gamma:boolean, flipY:boolean)");
+    return read_u8(env, info, ptx_read_compat_rgba8, "ptx_napi: readCompatRgba8(handle, gamma:boolean, flipY:boolean)");
 }
 
-/* writeSum(handle, width, height, Float32Array rgb (W*H*3), framesDone): checkpoint restore */
+/* writeSum(handle, Float32Array rgb (W*H*3 of the context's size), framesDone): checkpoint restore */
 static napi_value WriteSum(napi_env env, napi_callback_info info) {
-    napi_value argv[5];
+    napi_value argv[3];
     uint32_t w = 0, h = 0, frames = 0;
-    if (!get_args(env, info, 5, argv)) return NULL;
+    if (!get_args(env, info, 3, argv)) return NULL;
     ptx_ctx *ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
-    if (napi_get_value_uint32(env, argv[1], &w) != napi_ok || napi_get_value_uint32(env, argv[2], &h) != napi_ok ||
-        napi_get_value_uint32(env, argv[4], &frames) != napi_ok) {
-        napi_throw_type_error(env, NULL, "ptx_napi: writeSum(handle, width, height, rgb:Float32Array, framesDone)");
+    if (!ctx || !get_size(env, ctx, &w, &h)) return NULL;
+    if (napi_get_value_uint32(env, argv[2], &frames) != napi_ok) {
+        napi_throw_type_error(env, NULL, "ptx_napi: writeSum(handle, rgb:Float32Array, framesDone)");
         return NULL;
     }
-    const float *rgb = (const float *)get_typed(env, argv[3], napi_float32_array, (size_t)w * h * 3, NULL, "rgb");
+    const float *rgb = (const float *)get_typed(env, argv[1], napi_float32_array, (size_t)w * h * 3, NULL, "rgb");
     if (!rgb) return NULL;
     int rc = ptx_write_sum_f32(ctx, rgb, frames);
     if (rc) return throw_ptx(env, ctx, rc);
@@ -411,13 +448,12 @@ static napi_value TraceClosest(napi_env env, napi_callback_info info) {
 }
 
 static napi_value PrimaryHits(napi_env env, napi_callback_info info) {
-    napi_value argv[3];
+    napi_value argv[1];
     uint32_t w = 0, h = 0;
     void *t = NULL, *tri = NULL;
-    if (!get_args(env, info, 3, argv)) return NULL;
+    if (!get_args(env, info, 1, argv)) return NULL;
     ptx_ctx *ctx = get_ctx(env, argv[0]);
-    if (!ctx) return NULL;
-    if (napi_get_value_uint32(env, argv[1], &w) != napi_ok || napi_get_value_uint32(env, argv[2], &h) != napi_ok) return NULL;
+    if (!ctx || !get_size(env, ctx, &w, &h)) return NULL;
     napi_value ta_t = make_typed(env, napi_float32_array, (size_t)w * h, 4, &t), ta_tri = make_typed(env, napi_int32_array, (size_t)w * h, 4, &tri);
     if (!ta_t || !ta_tri) return NULL;
     int rc = ptx_primary_hits(ctx, (int32_t *)tri, (float *)t);
@@ -442,6 +478,15 @@ static napi_value Counters(napi_env env, napi_callback_info info) {
     return o;
 }
 
+static napi_value CommWorld(napi_env env, napi_callback_info info) {
+    napi_value argv[1], r;
+    if (!get_args(env, info, 1, argv)) return NULL;
+    ptx_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return NULL;
+    NAPI_OK(env, napi_create_int32(env, ptx_comm_world(ctx), &r));
+    return r;
+}
+
 static napi_value ResetCounters(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return NULL;
@@ -457,7 +502,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"deviceCount", DeviceCount}, {"create", Create}, {"destroy", Destroy}, {"uploadScene", UploadScene}, {"setParams", SetParams},
         {"setOption", SetOption}, {"renderFrames", RenderFrames}, {"renderFramesAsync", RenderFramesAsync}, {"resetAccum", ResetAccum}, {"framesDone", FramesDone},
         {"readLinear", ReadLinear}, {"readSum", ReadSum}, {"readRgba8", ReadRgba8}, {"readCompatRgba8", ReadCompatRgba8}, {"writeSum", WriteSum}, {"traceClosest", TraceClosest},
-        {"primaryHits", PrimaryHits}, {"counters", Counters}, {"resetCounters", ResetCounters}};
+        {"primaryHits", PrimaryHits}, {"counters", Counters}, {"commWorld", CommWorld}, {"resetCounters", ResetCounters}};
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok ||

@@ -2,7 +2,9 @@
 
 Every (pixel, frame) is independent and frames differ only in `timestamp`, so rank r of G renders frames
 {r, r+G, ...} of the timestamp list over the FULL image into its own float accumulation buffer; the buffers are
-summed by one all-reduce (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in CPU tests).  Splitting the
+summed by one all-reduce: the library's own RCCL communicator when the context has one (ptx_comm_init / ptx_allreduce,
+include/ptx.h; init_library_comm below hands the id round over torch.distributed), else torch.distributed on the exported
+buffer (backend "nccl" = RCCL over xGMI; "gloo", staged through the host, in CPU tests and one-GPU rehearsals).  Splitting the
 samples of one frame across GPUs would not be reference-equivalent (the clamp applies to the frame mean and the
 seed chains through a pixel's samples, glsl:520-529) -- the split is by frame.
 """
@@ -21,6 +23,19 @@ def allreduce_sum(tensor, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
     return tensor
+
+
+def init_library_comm(ctx, group=None):
+    """Creates the library's RCCL communicator on `ctx` for the ranks of the torch.distributed group: rank 0 draws the id
+    (ptx_comm_unique_id), the group broadcasts its 128 bytes, every rank calls ptx_comm_init.  Returns the rank count RCCL
+    reports.  Collective: every rank of the group must call it."""
+    import torch.distributed as dist
+    from . import binding
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [binding.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ctx.comm_init(box[0], rank, world)
+    return ctx.comm_world
 
 
 def render_frames_distributed(ctx, timestamps, batch=None, on_batch=None, group=None):
@@ -46,10 +61,16 @@ def render_frames_distributed(ctx, timestamps, batch=None, on_batch=None, group=
     ts = np.ascontiguousarray(timestamps, dtype=np.int32)
     mine = frames_for_rank(len(ts), rank, world)
     dev = torch.device("cuda", ctx.device)
-    buf = torch.zeros(ctx.params.height, ctx.params.width, 4, dtype=torch.float32, device=dev)
+    # torch.empty: nothing of torch's is queued on this buffer, so the library's stream can write it at once (a zero-fill
+    # on torch's stream could land after a copy made on the context's own stream)
+    buf = torch.empty(ctx.params.height, ctx.params.width, 4, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
     on_device = multi and dist.get_backend(group) == "nccl"
+    library_comm = multi and ctx.comm_world == world          # ptx_comm_init was called for this group
 
     def reduce_into_buf():
+        if library_comm:                                       # one grouped ncclAllReduce inside the library, into buf
+            return ctx.allreduce(buf.data_ptr())
         ctx.accum_export_device(buf.data_ptr())
         ctx.synchronize()
         done = torch.tensor([ctx.frames_done], dtype=torch.int64, device=dev if on_device else "cpu")

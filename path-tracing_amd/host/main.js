@@ -11,8 +11,12 @@
  *
  *   node main.js --scene file.gltf|file.obj|file.ptxs [--camera preset | --camera-json file] [--width 256]
  *        [--height 256] [--frames 5] [--spp 5] [--bounces 5] [--out image.png|.ppm] [--dump-sum file.f32]
- *        [--device 0] [--traversal 0..3] [--save-scene out.ptxs] [--light-material name]
+ *        [--device 0 | --gpus N | --devices 0,1,...] [--traversal 0..3] [--save-scene out.ptxs] [--light-material name]
  *        [--checkpoint file.ptxc] [--checkpoint-every 16] [--compat-out image.png [--compat-rules 1|2] [--compat-gamma 0|1]]
+ * --gpus N (devices 0 .. N-1) or --devices a,b,...: one PathTracer over several GPUs.  Frame f of every renderFrames call
+ *   goes to device f mod N over the full image, the devices render side by side, and the per-device float buffers are
+ *   summed by one RCCL all-reduce when the image (or a checkpoint) is read -- the reference's frame loop (main.js:391-438)
+ *   for a whole node.  The same device listed N times rehearses that path on one GPU (summed by a kernel, no RCCL).
  * --checkpoint: progressive rendering like renderAsync (main.js:391-436): frames are rendered in batches of
  *   --checkpoint-every; after each batch {sum buffer, frames done} is written to the file (atomically, via rename).  If
  *   the file exists when the program starts, rendering resumes after the frames it holds (same size required); the
@@ -60,7 +64,13 @@ function main() {
     camera = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_right, cameraLeftBottom: c.cam_left_bottom };
   } else camera = cameraFromPreset(a.camera, a.width, a.height).getCamera();
 
-  const pt = new PathTracer(a.device);
+  let devices = a.device;
+  if (a.devices !== undefined) devices = String(a.devices).split(',').map((d) => parseInt(d, 10));
+  else if (a.gpus !== undefined && a.gpus > 1) devices = Array.from({ length: a.gpus }, (_, g) => g);
+  if (Array.isArray(devices) && devices.length === 1) devices = devices[0];
+  if (Array.isArray(devices) && a.compatOut) throw new Error('--compat-out needs a single device (the 8-bit blend is sequential over frames)');
+  const pt = new PathTracer(devices);
+  if (Array.isArray(devices)) console.log('devices: ' + devices.join(',') + ' (all-reduce over ' + pt.commWorld + ' ranks)');
   pt.uploadScene(scene);
   pt.setParams(a.width, a.height, camera, a.bounces, a.spp);
   if (a.traversal !== undefined) pt.setOption('traversal', a.traversal);

@@ -16,14 +16,17 @@ function loadAddon() {
 }
 
 class PathTracer {
+  /** device: one HIP device ordinal, or an array of them: one PathTracer over several GPUs (frames are dealt round-robin
+   *  to the devices and the per-device float buffers are summed by one RCCL all-reduce when the image is read;
+   *  include/ptx.h ptx_create). */
   constructor(device) {
     this.addon = loadAddon();
-    this.handle = this.addon.create(device || 0);
+    this.handle = this.addon.create(Array.isArray(device) ? device.map((d) => d | 0) : (device || 0));
     this.width = 0; this.height = 0;
     this._busy = false;
     // one context, one thread: while an async render runs on the libuv pool, calls from the event loop are refused
     for (const name of Object.getOwnPropertyNames(PathTracer.prototype)) {
-      if (name === 'constructor' || name === 'renderFramesAsync' || name === 'framesDone') continue;
+      if (name === 'constructor' || name === 'renderFramesAsync') continue;
       const fn = this[name];
       if (typeof fn !== 'function') continue;
       this[name] = (...args) => {
@@ -60,16 +63,19 @@ class PathTracer {
   }
   resetAccum() { this.addon.resetAccum(this.handle); }
   get framesDone() { return this.addon.framesDone(this.handle); }
-  readLinear() { return this.addon.readLinear(this.handle, this.width, this.height); }
-  readSum() { return this.addon.readSum(this.handle, this.width, this.height); }
-  readRgba8(gamma, flipY) { return this.addon.readRgba8(this.handle, this.width, this.height, gamma !== false, flipY !== false); }
+  /** devices (ranks) whose buffers the all-reduce sums: the device count of a multi-GPU PathTracer, else 0 */
+  get commWorld() { return this.addon.commWorld(this.handle); }
+  // read-back buffers are sized by the addon from the context's own width and height
+  readLinear() { return this.addon.readLinear(this.handle); }
+  readSum() { return this.addon.readSum(this.handle); }
+  readRgba8(gamma, flipY) { return this.addon.readRgba8(this.handle, gamma !== false, flipY !== false); }
   /** The reference's RGBA8 ping-pong target (setOption('compat_rgba8', 1 | 2) before rendering): what gl.readPixels returns in the browser
    *  (1 = GL's preferred store / NEAREST rules, 2 = SwiftShader's; include/ptx.h). */
-  readCompatRgba8(gamma, flipY) { return this.addon.readCompatRgba8(this.handle, this.width, this.height, gamma === true, flipY === true); }
+  readCompatRgba8(gamma, flipY) { return this.addon.readCompatRgba8(this.handle, gamma === true, flipY === true); }
   /** Checkpoint restore: accumulation := sum (Float32Array W*H*3 from readSum()), holding framesDone frames. */
-  writeSum(sum, framesDone) { this.addon.writeSum(this.handle, this.width, this.height, sum, framesDone); }
+  writeSum(sum, framesDone) { this.addon.writeSum(this.handle, sum, framesDone); }
   traceClosest(origins, directions) { return this.addon.traceClosest(this.handle, Float32Array.from(origins), Float32Array.from(directions)); }
-  primaryHits() { return this.addon.primaryHits(this.handle, this.width, this.height); }
+  primaryHits() { return this.addon.primaryHits(this.handle); }
   counters() { return this.addon.counters(this.handle); }
   resetCounters() { this.addon.resetCounters(this.handle); }
   destroy() { if (this.handle) { this.addon.destroy(this.handle); this.handle = null; } }

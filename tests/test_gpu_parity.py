@@ -405,7 +405,10 @@ def test_device_export_import_for_allreduce(gpu_ctx, ptx):
 def test_error_behaviour(ptx):
     b = ptx.binding
     lib = ptx.load_library()
-    assert lib.ptx_create((C.c_int * 2)(0, 0), 2) is None and b"one" in lib.ptx_last_error(None)
+    assert lib.ptx_create((C.c_int * 3)(0, 0, 1), 3) is None and b"distinct" in lib.ptx_last_error(None)   # neither all distinct nor all equal
+    assert lib.ptx_create((C.c_int * 1)(0), 0) is None and lib.ptx_create(None, 1) is None
+    with pytest.raises(ptx.PtxError):
+        ptx.Context(0).read_sum()                                     # read before set_params: a clear error
     with pytest.raises(ptx.PtxError):
         ptx.Context(99)
     ctx = ptx.Context(0)

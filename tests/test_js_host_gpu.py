@@ -86,6 +86,10 @@ const cam = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_ri
   let guarded = false, second = false;
   try { pt.readSum(); } catch (e) { guarded = /while renderFramesAsync is running/.test(e.message); }   // one context, one thread
   try { await pt.renderFramesAsync([1], 0); } catch (e) { second = /still running/.test(e.message); }
+  // past the JS wrapper, straight at the addon: the handle itself is marked busy and held alive by the job
+  let addonBusy = 0;
+  try { pt.addon.readSum(pt.handle); } catch (e) { addonBusy += /busy/.test(e.message) ? 1 : 0; }
+  try { pt.addon.destroy(pt.handle); } catch (e) { addonBusy += /destroy.. while/.test(e.message) ? 1 : 0; }
   await pending;
   clearInterval(timer);
   const b = pt.readSum();
@@ -93,7 +97,7 @@ const cam = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_ri
   for (let i = 0; same && i < a.length; i++) same = Object.is(a[i], b[i]);
   let rejected = false;
   try { await pt.addon.renderFramesAsync(pt.handle, new Float32Array(2), 0); } catch (e) { rejected = true; }
-  console.log(JSON.stringify({ same, frames: pt.framesDone, rejected, guarded, second }));
+  console.log(JSON.stringify({ same, frames: pt.framesDone, rejected, guarded, second, addonBusy, len: b.length }));
   pt.destroy();
 })().catch((e) => { console.error(e); process.exit(1); });
 """ % ROOT
@@ -101,7 +105,28 @@ const cam = { cameraSource: c.cam_src, cameraUp: c.cam_up, cameraRight: c.cam_ri
     f.write_text(js)
     import json
     out = json.loads(subprocess.check_output(["node", str(f)]).decode().strip().splitlines()[-1])
-    assert out == {"same": True, "frames": 3, "rejected": True, "guarded": True, "second": True}
+    assert out == {"same": True, "frames": 3, "rejected": True, "guarded": True, "second": True, "addonBusy": 2, "len": 64 * 48 * 3}
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")
+def test_node_cli_multi_device_equals_python_multi_device(ptx, tmp_path):
+    """`--devices 0,0,0`: the JS host drives one PathTracer over several devices (here one GPU listed three times: the
+    rehearsal form, summed by a kernel) -- same bytes as the ctypes path over the same device list, frames_done summed."""
+    name, w, h, spp, b, nfr = "my_cornell_6", 40, 24, 3, 4, 7
+    out = str(tmp_path / "sum.f32")
+    scenes = os.path.join(ROOT, "tests", "golden", "scenes")
+    log = subprocess.check_output(["node", os.path.join(ROOT, "path-tracing_amd", "host", "main.js"), "--scene", os.path.join(scenes, name + ".ptxs"),
+                                   "--camera-json", os.path.join(scenes, name + ".json"), "--width", str(w), "--height", str(h), "--frames", str(nfr),
+                                   "--spp", str(spp), "--bounces", str(b), "--dump-sum", out, "--devices", "0,0,0"]).decode()
+    assert "all-reduce over 3 ranks" in log
+    got = np.fromfile(out, dtype=np.float32).reshape(h, w, 3)
+    with ptx.Context([0, 0, 0]) as ctx:
+        ctx.upload_scene(ptx.load_scene(name))
+        ctx.set_params(ptx.config_params(name, w, h, spp, b))
+        ctx.render_frames(ptx.scene.timestamps(nfr))
+        want = ctx.read_sum()
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
 
 
 @pytest.mark.skipif(shutil.which("node") is None, reason="node not installed")

@@ -70,6 +70,39 @@ STREAM3(k_mullo, L_MULLO)
 STREAM3(k_cndmask, L_CNDMASK)
 STREAM3(k_cmp, L_CMP)
 STREAM3(k_mov, L_MOV)
+// second batch: the rest of the renderer's instruction mix
+#define L_MIN(r) "v_min_f32 " #r ", " #r ", %9\n"
+#define L_MAX3(r) "v_max3_f32 " #r ", " #r ", %8, %9\n"
+#define L_MIN3(r) "v_min3_f32 " #r ", " #r ", %8, %9\n"
+#define L_SUB(r) "v_sub_f32 " #r ", " #r ", %9\n"
+#define L_AND(r) "v_and_b32 " #r ", " #r ", %8\n"
+#define L_XOR(r) "v_xor_b32 " #r ", " #r ", %8\n"
+#define L_LSHL(r) "v_lshlrev_b32 " #r ", 1, " #r "\n"
+#define L_ADDU(r) "v_add_u32 " #r ", " #r ", %8\n"
+#define L_MAD24(r) "v_mad_u32_u24 " #r ", " #r ", %8, %9\n"
+#define L_MUL24(r) "v_mul_u32_u24 " #r ", " #r ", %8\n"
+#define L_CVT(r) "v_cvt_f32_i32 " #r ", " #r "\n"
+#define L_BFE(r) "v_bfe_u32 " #r ", " #r ", 3, 8\n"
+#define L_CND64(r) "v_cndmask_b32_e64 " #r ", " #r ", %8, s[20:21]\n"
+#define L_CMPCND(r) "v_cmp_lt_f32 vcc, " #r ", %8\n v_cndmask_b32 " #r ", " #r ", %9, vcc\n"
+#define L_CMPS(r) "v_cmp_lt_f32 s[20:21], " #r ", %8\n"
+#define L_CMPX(r) "v_cmp_class_f32 vcc, " #r ", %8\n"
+#define L_BPERM(r) "ds_bpermute_b32 " #r ", %8, " #r "\n s_waitcnt lgkmcnt(4)\n"
+#define L_FMAMIX(r) "v_fma_f32 " #r ", " #r ", %8, %9\n v_max_f32 " #r ", " #r ", %9\n"
+STREAM3(k_min, L_MIN)
+STREAM3(k_max3, L_MAX3)
+STREAM3(k_min3, L_MIN3)
+STREAM3(k_sub, L_SUB)
+STREAM3(k_and, L_AND)
+STREAM3(k_xor, L_XOR)
+STREAM3(k_lshl, L_LSHL)
+STREAM3(k_addu, L_ADDU)
+STREAM3(k_mad24, L_MAD24)
+STREAM3(k_mul24, L_MUL24)
+STREAM3(k_cvt, L_CVT)
+STREAM3(k_bfe, L_BFE)
+STREAM3(k_cmpcnd, L_CMPCND)
+STREAM3(k_fmamax, L_FMAMIX)
 
 // packed f32: 64-bit register pairs
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -113,7 +146,7 @@ STREAM_PK(k_pk_fma, L_PKFMA)
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                \
         for (int i = 0; i < iters; i++)                                                                            \
             asm volatile(".rept 16\n" line(%0) line(%1) line(%2) line(%3) line(%4) line(%5) line(%6) line(%7) ".endr\n" \
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s20", "scc"); \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "s20", "s21", "scc", "vcc"); \
         __builtin_amdgcn_s_waitcnt(0);                                                                             \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                \
         const unsigned long long w1 = wall_clock64();                                                              \
@@ -125,6 +158,9 @@ STREAM_PK(k_pk_fma, L_PKFMA)
         sink[blockIdx.x * 64 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));                   \
     }
 STREAM_S(k_fma_salu, L_FMA_S)
+STREAM_S(k_cnd64, L_CND64)
+STREAM_S(k_cmps, L_CMPS)
+STREAM_S(k_bperm, L_BPERM)
 
 typedef void (*kern_t)(Stamp*, float*, int);
 struct Case { const char* name; kern_t k; int valu_per_line; };
@@ -137,7 +173,14 @@ int main(int argc, char** argv) {
     const Case cases[] = {{"v_fma_f32", k_fma, 1}, {"v_mul_f32", k_mul, 1}, {"v_add_f32", k_add, 1}, {"v_max_f32", k_max, 1}, {"v_mov_b32", k_mov, 1},
                           {"v_cndmask_b32", k_cndmask, 1}, {"v_cmp_lt_f32", k_cmp, 1}, {"v_pk_mul_f32", k_pk_mul, 1}, {"v_pk_add_f32", k_pk_add, 1},
                           {"v_pk_fma_f32", k_pk_fma, 1}, {"v_mul_lo_u32", k_mullo, 1}, {"v_rcp_f32", k_rcp, 1}, {"v_sqrt_f32", k_sqrt, 1},
-                          {"v_fma_f32 + s_add_u32", k_fma_salu, 1}};
+                          {"v_fma_f32 + s_add_u32", k_fma_salu, 1},
+                          {"v_min_f32", k_min, 1}, {"v_max3_f32", k_max3, 1}, {"v_min3_f32", k_min3, 1}, {"v_sub_f32", k_sub, 1}, {"v_and_b32", k_and, 1},
+                          {"v_xor_b32", k_xor, 1}, {"v_lshlrev_b32", k_lshl, 1}, {"v_add_u32", k_addu, 1}, {"v_mad_u32_u24", k_mad24, 1},
+                          {"v_mul_u32_u24", k_mul24, 1}, {"v_cvt_f32_i32", k_cvt, 1}, {"v_bfe_u32", k_bfe, 1},
+                          {"v_cndmask_b32_e64 (sgpr mask)", k_cnd64, 1}, {"v_cmp_lt_f32 -> sgpr pair", k_cmps, 1},
+                          {"PAIR v_cmp_lt_f32 vcc + v_cndmask_b32 (per pair)", k_cmpcnd, 1}, {"PAIR v_fma_f32 + v_max_f32 (per pair)", k_fmamax, 1},
+                          {"ds_bpermute_b32", k_bperm, 1}};
+    const char* only = argc > 2 ? argv[2] : nullptr;                // "new": just the second batch
     const int waves_per_simd[] = {1, 2, 4, 5, 8};
     const size_t max_blocks = (size_t)simds * 8;
     Stamp* d_st; float* d_sink;
@@ -147,8 +190,15 @@ int main(int argc, char** argv) {
     printf("{\"device\": \"%s\", \"cus\": %d, \"simds\": %d, \"clock_rate_khz\": %d, \"instructions_per_wave\": %lld, \"results\": [\n", prop.gcnArchName, cus, simds,
            prop.clockRate, (long long)iters * PER_ITER);
     bool first = true;
+    int case_index = 0;
     for (const Case& c : cases) {
+        if (only && std::string(only) == "new" && case_index++ < 14) continue;
+        // "calib": three streams at 1 and 5 waves per SIMD, to be run under rocprofv3 --pmc: what do SQ_ACTIVE_INST_VALU and
+        // SQ_BUSY_CYCLES read for a stream whose issue rate is known?
+        const bool calib = only && std::string(only) == "calib";
+        if (calib && std::string(c.name) != "v_fma_f32" && std::string(c.name) != "v_max_f32" && std::string(c.name) != "v_pk_mul_f32") continue;
         for (int W : waves_per_simd) {
+            if (calib && W != 1 && W != 5) continue;
             const int blocks = simds * W;
             hipLaunchKernelGGL(c.k, dim3(blocks), dim3(64), 0, 0, d_st, d_sink, 64);       // warm-up (code load, clocks)
             CHECK(hipDeviceSynchronize());
