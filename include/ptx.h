@@ -115,9 +115,25 @@ int ptx_upload_scene(ptx_ctx *ctx, const ptx_scene *scene);
 /* Replaces the uniform block of main.js:290-308. Resets the accumulation when the size changes. */
 int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
 /* Tuning / test switches (no reference counterpart). Keys:
- *   "traversal" : bit 0 = conservative best-t pruning, bit 1 = walk the leaf-SAH tree (same leaves, same results,
- *                 about half the box tests; DESIGN.md "Leaf-SAH tree").  0 = literal threaded traversal of
- *                 glsl:207-249 on the reference tree, 1 = + pruning, 2 = leaf-SAH tree, 3 = both (default)
+ *   "traversal" : bit 0 = best-t pruning (nodes that cannot hold a closer hit are skipped; the rule is option "prune"),
+ *                 bit 1 = walk the leaf-SAH tree (same leaves, same results, about half the box tests; DESIGN.md
+ *                 "Leaf-SAH tree").  0 = literal threaded traversal of glsl:207-249 on the reference tree, 1 = + pruning,
+ *                 2 = leaf-SAH tree, 3 = both (default)
+ *   "prune"     : the pruning rule of traversal bit 0 for BOUNCE rays (primary rays are always traced unpruned, so the
+ *                 primary hit of every pixel is the reference's closest hit unconditionally).
+ *                 2 (default) = margin rule: a node is skipped when its box is entered beyond 1.001 * best + 0.001.  Every
+ *                 frame rendered with it so far equals the unpruned reference bit for bit (all fixtures, whole 1080p / 4K
+ *                 frames of every BASELINE scene), but it is NOT exact for every conceivable ray: the shader's triangle test
+ *                 becomes ill-conditioned for a hit that grazes a large triangle within ~1e-3 rad, and if such a hit's
+ *                 computed t falls below the true box entry by more than the margin while another hit lies in between, the
+ *                 pruned walk returns that other hit.  ptx_selfcheck_pruning constructs such rays (a few per 10^7
+ *                 adversarial ones; none occur in the renders compared).
+ *                 1 = provable rule: a node is skipped only when a rounding-error bound of the shader's own triangle test
+ *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
+ *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles
+ *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned (headline:
+ *                 1.45 x the time of rule 2, 2 % faster than traversal = 2).  Callers that need the guarantee use it or
+ *                 traversal = 2.
  *   "memo"      : 1 = reuse the per-pixel primary hit and the last light-attempt ray for the shadow ray
  *                 (default; both are bit-identical rays in the reference), 0 = trace every ray
  *   "count"     : 1 = also count node visits / triangle tests (slower), 0 = off (default)
@@ -184,6 +200,21 @@ int ptx_write_sum_f32(ptx_ctx *ctx, const float *rgb, uint32_t frames_done);
 /* Closest hit of n rays (o, d: 3n floats) by ray_bvh_intersection_hit_miss (glsl:207-249). A miss gives
  * t = 1e38f, tri_id = -1; a hit gives the ORIGINAL triangle index (inorder_tri[k]) of the winner. */
 int ptx_trace_closest(ptx_ctx *ctx, const float *o, const float *d, uint32_t n, float *t, int32_t *tri_id);
+/* Check of option "traversal" bit 0 (best-t pruning; the reference never prunes, glsl:207-249) under the rule option "prune"
+ * selects -- a machine check beside the proof for prune = 1, the measure of what prune = 2 gives up: generates n_rays adversarial rays of one family ON THE DEVICE (0 surface -> any
+ * direction, 1 surface -> surface, 2 in the own triangle's plane +- a tiny tilt, 3 grazing one of the 256 largest triangles
+ * from afar, 4 skimming a triangle's bounding-box face from just outside its slab, 5 grazing hemisphere directions, 6 (nearly)
+ * axis-parallel, 7 towards vertices and edges), traces each one with and without pruning through the tree the "traversal"
+ * option selects (bit 1) with the arithmetic of the selected pipeline, and reports how many (t bits, triangle) results
+ * differ, with the first 16 offenders (o.xyz, d.xyz, t exact, t pruned; triangle exact, triangle pruned).
+ * tests/test_prune_certificate.py runs >= 1e8 rays per BASELINE scene: zero differences under prune = 1; under prune = 2
+ * family 3 finds the grazing rays described at option "prune". */
+typedef struct ptx_selfcheck_result {
+    uint64_t rays, hits, mismatches;
+    float first[16][8];
+    int32_t first_tri[16][2]; /* -2 = unused entry */
+} ptx_selfcheck_result;
+int ptx_selfcheck_pruning(ptx_ctx *ctx, uint32_t family, uint64_t n_rays, uint32_t seed, ptx_selfcheck_result *out);
 /* Primary-ray closest hits for every pixel (glsl:501-514 + 207-249); W*H entries, row 0 = bottom. */
 int ptx_primary_hits(ptx_ctx *ctx, int32_t *tri_id, float *t);
 /* Primary ray directions (glsl:145-148, 501-514); dirs: W*H*3 floats. */

@@ -24,7 +24,7 @@ SYMBOLS = ["ptx_device_count", "ptx_create", "ptx_destroy", "ptx_last_error", "p
            "ptx_set_option", "ptx_render_frames", "ptx_render_frames_noalloc", "ptx_synchronize", "ptx_reset_accum", "ptx_frames_done",
            "ptx_read_linear_f32", "ptx_read_sum_f32", "ptx_read_rgba8", "ptx_read_compat_rgba8", "ptx_write_sum_f32", "ptx_trace_closest", "ptx_primary_hits",
            "ptx_primary_dirs", "ptx_get_counters", "ptx_reset_counters", "ptx_accum_export_device",
-           "ptx_accum_import_device", "ptx_get_size", "ptx_comm_unique_id", "ptx_comm_init", "ptx_comm_world", "ptx_allreduce"]
+           "ptx_accum_import_device", "ptx_get_size", "ptx_comm_unique_id", "ptx_comm_init", "ptx_comm_world", "ptx_allreduce", "ptx_selfcheck_pruning"]
 
 
 class PtxError(RuntimeError):
@@ -53,6 +53,10 @@ class CCounters(C.Structure):
         d = {n: (float(getattr(self, n)) if n == "kernel_ms" else int(getattr(self, n))) for n, _ in self._fields_ if n != "diag"}
         d["diag"] = [int(x) for x in self.diag]
         return d
+
+
+class CSelfcheck(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("hits", C.c_uint64), ("mismatches", C.c_uint64), ("first", (C.c_float * 8) * 16), ("first_tri", (C.c_int32 * 2) * 16)]
 
 
 def lib_path():
@@ -103,6 +107,7 @@ def load_library():
     L.ptx_reset_counters.argtypes = [C.c_void_p]
     L.ptx_accum_export_device.argtypes = [C.c_void_p, C.c_void_p]
     L.ptx_accum_import_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.ptx_selfcheck_pruning.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(CSelfcheck)]
     L.ptx_get_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.ptx_comm_unique_id.argtypes = [C.c_void_p]
     L.ptx_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -251,6 +256,18 @@ class Context:
         tri = np.zeros(n, dtype=np.int32)
         self._check(self._lib.ptx_trace_closest(self._h, _fp(o), _fp(d), n, _fp(t), _ip(tri)))
         return t, tri
+
+    def selfcheck_pruning(self, family, n_rays, seed=1):
+        """ptx_selfcheck_pruning: n_rays adversarial rays of `family`, traced with and without pruning on the device.
+        Returns dict(rays, hits, mismatches, first=[(o, d, t_exact, t_pruned, tri_exact, tri_pruned), ...])."""
+        r = CSelfcheck()
+        self._check(self._lib.ptx_selfcheck_pruning(self._h, int(family), int(n_rays), int(seed), C.byref(r)))
+        first = []
+        for q in range(16):
+            if r.first_tri[q][0] != -2 or r.first_tri[q][1] != -2:
+                v = [float(x) for x in r.first[q]]
+                first.append((v[0:3], v[3:6], v[6], v[7], int(r.first_tri[q][0]), int(r.first_tri[q][1])))
+        return {"rays": int(r.rays), "hits": int(r.hits), "mismatches": int(r.mismatches), "first": first}
 
     def primary_hits(self):
         tri = np.zeros((self.params.height, self.params.width), dtype=np.int32)

@@ -22,7 +22,7 @@ using namespace ptx;
 // ------------------------------------------------------------------------------------------ kernels
 
 // Primary-hit cache: one thread per pixel, 8x8 tiles (glsl:501-514 + 207-249).
-template <bool PRUNE>
+template <int PRUNE>
 __global__ __launch_bounds__(64) void k_primary(DScene S, DParams P, float* __restrict__ prim_t, int* __restrict__ prim_tri,
                                                 float4* __restrict__ dirs) {
     uint32_t px, py;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64) void k_primary(DScene S, DParams P, float* __re
 }
 
 // Test hook: closest hit of arbitrary rays (glsl:207-249), one thread per ray.
-template <bool PRUNE, bool PAIRS>
+template <int PRUNE, bool PAIRS>
 __global__ __launch_bounds__(64) void k_trace(DScene S, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
                                               float* __restrict__ t_out, int* __restrict__ tri_out, unsigned long long* counters) {
     const uint32_t i = blockIdx.x * 64u + threadIdx.x;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void k_trace(DScene S, const float* __restrict_
 
 // The path tracer: one thread per (pixel, frame-in-batch); one wave = one 8x8 pixel tile of one frame.
 // Writes the frame's clamp(mean) into fb[frame][pixel]; k_accumulate folds the batch in frame order.
-template <bool PRUNE, bool MEMO, bool COUNT>
+template <int PRUNE, bool MEMO, bool COUNT>
 __global__ __launch_bounds__(64) void k_render(DScene S, DParams P, const int32_t* __restrict__ timestamps,
                                                const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
                                                float4* __restrict__ fb, unsigned long long* counters) {
@@ -181,6 +181,118 @@ __global__ __launch_bounds__(64) void k_store_timestamps(TsBlock ts, int32_t* __
     if (threadIdx.x < n) dst[threadIdx.x] = ts.v[threadIdx.x];
 }
 
+// ---- ptx_selfcheck_pruning: the certificate behind option "traversal" bit 0 (DESIGN.md "Pruning and exactness")
+// Every thread generates one ADVERSARIAL ray from a counter-based hash (no host traffic, so 10^8 rays take a fraction of a
+// second) and traces it twice through the same tree: once without pruning (exact by construction) and once with it.  Any
+// difference in (t bits, triangle) is counted and the first 16 are recorded.  Families (each biased towards what could
+// break a best-t cut: hits whose Moeller-Trumbore t is ill-conditioned, boxes entered at grazing angles, ties):
+//   0 surface point -> uniform direction            4 skimming a triangle's bounding-box face from just outside the slab
+//   1 surface point -> point on another triangle    5 grazing directions of the hemisphere about the surface's own normal
+//   2 in the plane of the own triangle +- tiny tilt 6 (nearly) axis-parallel rays: huge / infinite 1/d components
+//   3 grazing a LARGE triangle from far away        7 surface point -> vertex / edge of another triangle
+struct CheckArgs { unsigned long long n; uint32_t seed, family, n_big; const uint32_t* big; V3 bmin, bmax; };
+struct CheckOut { unsigned long long rays, hits, mismatches; float first[16][8]; int first_tri[16][2]; };
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+struct CheckRng {
+    uint32_t s;
+    __device__ __forceinline__ uint32_t u() { s = hash32(s + 0x9E3779B9u); return s; }
+    __device__ __forceinline__ float f() { return (float)(u() >> 8) * (1.0f / 16777216.0f); }              // [0, 1)
+    __device__ __forceinline__ float sgn() { return (u() & 1u) ? 1.0f : -1.0f; }
+    __device__ __forceinline__ float tiny(float lo_exp, float span) { return exp2f(-(lo_exp + span * f())); }  // log-uniform 2^-lo .. 2^-(lo+span)
+};
+
+template <int PRUNE, bool PAIRS>
+__global__ __launch_bounds__(64) void k_selfcheck(DScene S, CheckArgs A, CheckOut* out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 64ull + threadIdx.x;
+    if (i >= A.n) return;
+    CheckRng R{hash32(A.seed ^ hash32((uint32_t)i) ^ hash32((uint32_t)(i >> 32) + 0x51ED27u) ^ (A.family * 0x9E3779B1u))};
+    const uint32_t T = (uint32_t)S.T;
+    auto tri = [&](uint32_t k, V3& v0, V3& e1, V3& e2) { v0 = mk(ld16(S.tris, k * 48u)); e1 = mk(ld16(S.tris, k * 48u + 16u)); e2 = mk(ld16(S.tris, k * 48u + 32u)); };
+    auto point_on = [&](V3 v0, V3 e1, V3 e2) { float a = R.f(), b = R.f(); if (a + b > 1.0f) { a = 1.0f - a; b = 1.0f - b; } return (v0 + e1 * a) + e2 * b; };
+    auto pick = [&](bool prefer_big) { return (prefer_big && A.n_big && (R.u() & 1u)) ? A.big[R.u() % A.n_big] : R.u() % T; };
+    const V3 ext = A.bmax - A.bmin;
+    const float scale = fmaxf(fmaxf(ext.x, ext.y), ext.z);
+    V3 a0, a1, a2;
+    tri(R.u() % T, a0, a1, a2);
+    V3 o = point_on(a0, a1, a2), d = mk(1.f, 0.f, 0.f);
+    const V3 nA = normalize(cross(a1, a2));
+    auto in_plane = [&](V3 e1, V3 e2) { return normalize(e1 * (R.f() - 0.5f) + e2 * (R.f() - 0.5f)); };
+    switch (A.family) {
+        case 0: {
+            const float z = 2.0f * R.f() - 1.0f, ph = 6.2831853f * R.f(), r = sqrtf(fmaxf(0.f, 1.0f - z * z));
+            d = mk(r * cosf(ph), r * sinf(ph), z);
+            break;
+        }
+        case 1: { V3 b0, b1, b2; tri(pick(true), b0, b1, b2); d = normalize(point_on(b0, b1, b2) - o); break; }
+        case 2: d = normalize(in_plane(a1, a2) + nA * (R.sgn() * R.tiny(1.f, 22.f))); break;
+        case 3: {
+            V3 b0, b1, b2; tri(pick(true), b0, b1, b2);
+            const V3 tgt = point_on(b0, b1, b2), w = in_plane(b1, b2), nB = normalize(cross(b1, b2));
+            const float L = scale * exp2f(-6.0f * R.f()), sn = R.tiny(4.f, 20.f);
+            o = (tgt - w * L) + nB * (R.sgn() * L * sn);
+            d = normalize(tgt - o);
+            break;
+        }
+        case 4: {
+            V3 b0, b1, b2; tri(pick(false), b0, b1, b2);
+            const V3 p1 = b0 + b1, p2 = b0 + b2;
+            const V3 lo = mk(fminf(fminf(b0.x, p1.x), p2.x), fminf(fminf(b0.y, p1.y), p2.y), fminf(fminf(b0.z, p1.z), p2.z));
+            const V3 hi = mk(fmaxf(fmaxf(b0.x, p1.x), p2.x), fmaxf(fmaxf(b0.y, p1.y), p2.y), fmaxf(fmaxf(b0.z, p1.z), p2.z));
+            const V3 tgt = point_on(b0, b1, b2);
+            const uint32_t k = R.u() % 3u;
+            const bool upper = (R.u() & 1u) != 0;
+            const float delta = scale * R.tiny(6.f, 18.f) * (upper ? 1.0f : -1.0f), L = scale * exp2f(-8.0f * R.f());
+            const float ph = 6.2831853f * R.f(), c = L * cosf(ph), sn = L * sinf(ph);
+            o = tgt;                                   // lateral offset in the two other axes, a hair outside the slab of axis k
+            if (k == 0) { o.x = (upper ? hi.x : lo.x) + delta; o.y += c; o.z += sn; }
+            else if (k == 1) { o.y = (upper ? hi.y : lo.y) + delta; o.z += c; o.x += sn; }
+            else { o.z = (upper ? hi.z : lo.z) + delta; o.x += c; o.y += sn; }
+            d = normalize(tgt - o);
+            break;
+        }
+        case 5: { const float z = R.tiny(1.f, 22.f); d = normalize(in_plane(a1, a2) * sqrtf(1.0f - z * z) + nA * z); break; }
+        case 6: {
+            const uint32_t k = R.u() % 3u, mode = R.u() % 3u;
+            const float e1 = mode == 0 ? 0.f : R.sgn() * R.tiny(10.f, 110.f), e2 = mode == 2 ? R.sgn() * R.tiny(10.f, 110.f) : 0.f, m = R.sgn();
+            d = k == 0 ? mk(m, e1, e2) : (k == 1 ? mk(e2, m, e1) : mk(e1, e2, m));
+            if (R.u() & 1u) o = mk(A.bmin.x + ext.x * R.f(), A.bmin.y + ext.y * R.f(), A.bmin.z + ext.z * R.f());
+            break;
+        }
+        default: {
+            V3 b0, b1, b2; tri(pick(true), b0, b1, b2);
+            const uint32_t w = R.u() % 6u;
+            const float s = R.f();
+            V3 tgt = w == 0 ? b0 : (w == 1 ? b0 + b1 : (w == 2 ? b0 + b2 : (w == 3 ? b0 + b1 * s : (w == 4 ? b0 + b2 * s : (b0 + b1 * s) + b2 * (1.0f - s)))));
+            d = normalize(tgt - o);
+            break;
+        }
+    }
+    LocalCnt c = {};
+    float t0, t1;
+    int k0, k1;
+    bool h0;
+    if (PAIRS) { h0 = closest_hit_pairs<0, false>(S, o, d, t0, k0, c); closest_hit_pairs<PRUNE, false>(S, o, d, t1, k1, c); }
+    else { h0 = closest_hit<0, false>(S, o, d, t0, k0, c); closest_hit<PRUNE, false>(S, o, d, t1, k1, c); }
+    const bool bad = __float_as_uint(t0) != __float_as_uint(t1) || k0 != k1;
+    const unsigned long long mh = __ballot(h0), mb = __ballot(bad), ma = __ballot(1);
+    if (first_active_lane()) {
+        atomicAdd(&out->rays, (unsigned long long)__popcll(ma));
+        atomicAdd(&out->hits, (unsigned long long)__popcll(mh));
+        if (mb) atomicAdd(&out->mismatches, (unsigned long long)__popcll(mb));
+    }
+    if (bad) {
+        for (int q = 0; q < 16; q++) {                       // claim the first free record
+            if (atomicCAS(&out->first_tri[q][0], -2, k0) == -2) {
+                out->first_tri[q][1] = k1;
+                const float rec[8] = {o.x, o.y, o.z, d.x, d.y, d.z, t0, t1};
+                for (int e = 0; e < 8; e++) out->first[q][e] = rec[e];
+                break;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host side
 
 struct ptx_ctx {
@@ -194,6 +306,9 @@ struct ptx_ctx {
     const float4* nodes_sah = nullptr;   // leaf-SAH tree over the reference leaves: 8 direction-octant layouts + the reference tree, or nullptr
     int N_sah = 0;
     std::vector<void*> scene_allocs;
+    float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};   // of all triangles (ptx_selfcheck_pruning aims rays with it)
+    const uint32_t* d_big_slots = nullptr;                     // inorder slots of the largest triangles, by area
+    uint32_t n_big_slots = 0;
 
     // params
     bool have_params = false;
@@ -216,6 +331,7 @@ struct ptx_ctx {
     size_t stage_cap = 0;
 
     // options
+    int opt_prune = 2;   // 2 = heuristic margin (default), 1 = provable pruning (option "prune"); applies when traversal bit 0 is set
     int opt_traversal = 3, opt_memo = 1, opt_count = 0, opt_pipeline = 2, opt_frame_batch = 0, opt_tasks_per_wave = 128, opt_compat = 0, opt_pool_chunk = 64;
 
     // multi-GPU (DESIGN.md "Multi-GPU")
@@ -231,7 +347,7 @@ struct ptx_ctx {
     // counters + timing
     unsigned long long* d_counters = nullptr;
     uint32_t* d_task_counter = nullptr;       // pipeline 2: next undrawn (pixel, frame) task of the running launch
-    uint64_t pool_resident[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pipeline 2: grid size per kernel variant (queried once)
+    uint64_t pool_resident[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // pipeline 2: grid size per kernel variant (queried once)
     bool pool_ok = true;                       // pipeline 2 needs disjoint leaf ranges (pair records are addressed by first slot)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<hipEvent_t> free_events;
@@ -260,7 +376,7 @@ static hipError_t scratch_for_device(int device, unsigned char** out) {   // `de
 }
 
 // traversal option: bit 0 = best-t pruning, bit 1 = walk the leaf-SAH tree instead of the reference tree
-static inline bool opt_prune(const ptx_ctx* c) { return (c->opt_traversal & 1) != 0; }
+static inline int prune_mode(const ptx_ctx* c) { return (c->opt_traversal & 1) ? c->opt_prune : 0; }   // the kernels' PRUNE parameter
 static inline DScene scene_view(const ptx_ctx* c) {
     DScene S = c->S;
     if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; S.oct_stride = (uint32_t)c->N_sah * 32u; S.ref_base = 8u * S.oct_stride; }
@@ -419,7 +535,57 @@ static int upload(ptx_ctx* ctx, const std::vector<T>& h, const T** out) {
 // exactly the same set of leaves with about half the box tests on pixar_room.  Leaves are visited in a different order,
 // so the winner among equal t is chosen by inorder slot explicitly (closest_hit's (t, k) compare).
 // Returns false when the reference arrays do not have that containment property (then the reference tree is walked).
-struct SahItem { float mn[3], mx[3]; int fc; float cen[3]; double w; };
+
+// ---- provable pruning (ptx_kernels.h, PRUNE = 1): the position-error coefficients of a triangle.
+// Claim (proof in DESIGN.md "Pruning and exactness"; u = 2^-24, strict binary32, the operation order of tri_test): let the
+// ray satisfy | |d|^2 - 1 | <= 1e-3 and let tri_test / tri_test2 (glsl:150-173) ACCEPT a hit on the triangle (v0, e1, e2)
+// with computed determinant a^ and distance t^.  With E = max(|e1|, |e2|) and any M >= max(|o - v0|, E):
+//     if 61 u M E <= |a^|:   the point o + t^ d lies within   (u / |a^|) * 90 E^2 M + 20 u M   of the triangle.
+// (Absolute errors: a^ within 7u E^2 of d . (e2 x e1); the three numerators within 8.1u M E^2 / {1, |e1|, |e2|}; two more
+// roundings in f = 1 / a^ and the product; accepted barycentrics u^, v^ >= 0, u^ + v^ <= 1 + 2u.)  Two ways to bound |a^|:
+//   * any accepted hit has |a^| >= eps0 = 0.0001f (glsl:156)             -> c_o = 1.01 (90 (u / eps0) E^2 + 20 u),
+//     valid when 61 (u / eps0) M_cap E <= 1, else inf (never pruned);
+//   * a triangle whose unit normal is within delta of +- N_j (a "class") has |a^| >= 2 area (|d . N_j| - delta') >= 2 area / w_ray
+//                                                                        -> c_c = 1.01 (90 u E^2 / (2 area) + 20 u), times w_ray,
+//     valid when E^2 / (2 area) <= 10 and 61 u M_cap E WCAP / (2 area) <= 1.
+// Every triangle is charged to ONE of the two: c_c when it is a class member and that is the smaller slack at w_ray = 1.
+struct TriCoef { float c_o, c_c; };
+static const double kU = 5.9604644775390625e-08, kEps0 = (double)0.0001f;
+static float coef_other_of(double E, double m_cap) {
+    if (!(61.0 * (kU / kEps0) * m_cap * E <= 1.0)) return INFINITY;
+    return (float)(1.01 * (90.0 * (kU / kEps0) * E * E + 20.0 * kU));
+}
+static float coef_class_of(double E, double area2, double m_cap) {      // inf: cannot be a class member
+    if (!(area2 > 0.0) || !(E * E / area2 <= 10.0) || !(61.0 * kU * m_cap * E * (double)PTX_CLS_WCAP / area2 <= 1.0)) return INFINITY;
+    return (float)(1.01 * (90.0 * kU * E * E / area2 + 20.0 * kU));
+}
+// 16-bit float (sign 0, 8-bit exponent, 7-bit mantissa), rounded UP; two of them make the packed word the kernels decode
+static uint32_t half_up(float c) {
+    if (!(c >= 0.f)) return 0x7FFFu;                                     // NaN: never pruned
+    uint32_t b; std::memcpy(&b, &c, 4);
+    return std::min<uint32_t>((b >> 16) + ((b & 0xFFFFu) ? 1u : 0u), 0x7F80u);   // at most +inf
+}
+static uint32_t pack_coefs(TriCoef c) { return (half_up(c.c_o) << 16) | half_up(c.c_c); }    // bit 31 clear; inner nodes set it
+struct SahItem { float mn[3], mx[3]; int fc; float cen[3]; double w; TriCoef coef; };
+
+// max of v over [lo, hi) for many ranges: a flat segment tree (the nodes a threaded walk skips when node i is cut are
+// exactly (i, miss[i]), whatever shape the caller's arrays have)
+struct RangeMax {
+    size_t n;
+    std::vector<float> t;
+    explicit RangeMax(const std::vector<float>& v) : n(v.size()), t(2 * v.size(), 0.f) {
+        std::copy(v.begin(), v.end(), t.begin() + n);
+        for (size_t i = n; i-- > 1;) t[i] = std::max(t[2 * i], t[2 * i + 1]);
+    }
+    float query(size_t lo, size_t hi) const {
+        float m = 0.f;
+        for (lo += n, hi += n; lo < hi; lo >>= 1, hi >>= 1) {
+            if (lo & 1) m = std::max(m, t[lo++]);
+            if (hi & 1) m = std::max(m, t[--hi]);
+        }
+        return m;
+    }
+};
 
 static bool ref_tree_is_monotone(const ptx_scene* sc) {
     const uint32_t N = sc->N;
@@ -447,7 +613,8 @@ static double half_area(const float* mn, const float* mx) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-struct SahNode { float mn[3], mx[3]; int fc; int left, right, axis; int parent; double q; /* P(box entered | parent entered), see sah_sample */ };
+struct SahNode { float mn[3], mx[3]; int fc; int left, right, axis; int parent; double q; /* P(box entered | parent entered), see sah_sample */
+                 TriCoef coef; /* largest coefficients beneath (provable pruning) */ };
 #ifndef PTX_SAH_CONTRACT_BIAS
 #define PTX_SAH_CONTRACT_BIAS 1.0   // 0 = keep every node; measured on the headline: 0.8 -> 91.9, 0.95 .. 1.0 -> 86.3, 1.1 -> 88.5, 1.3 -> 92.0 ms
 #endif
@@ -460,9 +627,10 @@ static int sah_build(std::vector<SahItem>& items, std::vector<uint32_t>& ids, si
     for (int k = 0; k < 3; k++) { nd.mn[k] = INFINITY; nd.mx[k] = -INFINITY; }
     for (size_t q = lo; q < hi; q++)
         for (int k = 0; k < 3; k++) { nd.mn[k] = std::min(nd.mn[k], items[ids[q]].mn[k]); nd.mx[k] = std::max(nd.mx[k], items[ids[q]].mx[k]); }
-    nd.fc = -2; nd.left = nd.right = -1; nd.axis = 0; nd.parent = -1; nd.q = 1.0;
+    nd.fc = -2; nd.left = nd.right = -1; nd.axis = 0; nd.parent = -1; nd.q = 1.0; nd.coef = {0.f, 0.f};
     if (hi - lo == 1) {
         nd.fc = items[ids[lo]].fc;
+        nd.coef = items[ids[lo]].coef;
     } else {
         const size_t n = hi - lo;
         double best = INFINITY; int best_axis = 0; size_t best_k = n / 2;
@@ -492,6 +660,7 @@ static int sah_build(std::vector<SahItem>& items, std::vector<uint32_t>& ids, si
         nd.left = sah_build(items, ids, lo, lo + best_k, tree);      // lower side along the split axis
         nd.right = sah_build(items, ids, lo + best_k, hi, tree);     // upper side
         tree[nd.left].parent = me; tree[nd.right].parent = me;
+        nd.coef = {std::max(tree[nd.left].coef.c_o, tree[nd.right].coef.c_o), std::max(tree[nd.left].coef.c_c, tree[nd.right].coef.c_c)};
     }
     tree[me] = nd;
     return me;
@@ -570,7 +739,7 @@ static void sah_sample(const ptx_scene* sc, std::vector<SahNode>& tree) {
                 const double t1 = ((double)nd.mn[k] - ray.o[k]) * ray.inv[k], t2 = ((double)nd.mx[k] - ray.o[k]) * ray.inv[k];
                 tn = std::max(tn, std::min(t1, t2)); tf = std::min(tf, std::max(t1, t2));
             }
-            if (!(tn <= tf && tf > 0) || tn > ray.limit) continue;
+            if (!(tn <= tf && tf > 0) || tn > ray.limit) continue;                   // the default rule (option "prune" = 2)
             ent[x]++;
             if (nd.left >= 0) {
                 const bool neg = ray.d[nd.axis] < 0;
@@ -650,7 +819,8 @@ static void sah_flatten(const std::vector<SahNode>& tree, SahPlan& pl, int node,
     }
     const size_t me = out.size() / 2 - base;
     out.push_back(make_float4(nd.mn[0], nd.mn[1], nd.mn[2], 0.f));
-    out.push_back(make_float4(nd.mx[0], nd.mx[1], nd.mx[2], bits(nd.fc)));
+    // leaves (and empty leaves, -2) keep fc; an inner node carries its packed coefficients under a set sign bit, so every "fc < 0" test holds
+    out.push_back(make_float4(nd.mx[0], nd.mx[1], nd.mx[2], bits(nd.left >= 0 ? (int32_t)(0x80000000u | pack_coefs(nd.coef)) : nd.fc)));
     if (nd.left >= 0) {
         sah_flatten(tree, pl, neg ? nd.right : nd.left, node, 1, oct, out, base);
         sah_flatten(tree, pl, neg ? nd.left : nd.right, node, 1, oct, out, base);
@@ -659,7 +829,7 @@ static void sah_flatten(const std::vector<SahNode>& tree, SahPlan& pl, int node,
 }
 
 // out: 8 layouts (one per direction octant) of N2 nodes each, same 32-B record format as the reference tree
-static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n2) {
+static bool build_leaf_sah(const ptx_scene* sc, const std::vector<TriCoef>& leaf_coef, std::vector<float4>& out, int* n2) {
     if (!ref_tree_is_monotone(sc)) return false;
     std::vector<SahItem> items;
     for (uint32_t i = 0; i < sc->N; i++) {
@@ -671,6 +841,7 @@ static bool build_leaf_sah(const ptx_scene* sc, std::vector<float4>& out, int* n
         }
         it.fc = sc->node_count[i] == 0 ? -2 : (sc->node_first[i] | (sc->node_count[i] << 24));
         it.w = std::max(1, sc->node_count[i]);
+        it.coef = leaf_coef[i];
         items.push_back(it);
     }
     if (items.empty()) return false;
@@ -766,6 +937,81 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         tris[3 * (size_t)k + 1] = make_float4(p[3] - p[0], p[4] - p[1], p[5] - p[2], 0.f); // glsl:151
         tris[3 * (size_t)k + 2] = make_float4(p[6] - p[0], p[7] - p[1], p[8] - p[2], 0.f); // glsl:152
     }
+    // ---- provable pruning: scene bounds, then one position-error coefficient per triangle, leaf and inner node (prune_coef)
+    float bmn[3] = {INFINITY, INFINITY, INFINITY}, bmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t q = 0; q < (size_t)T * 9; q++) { bmn[q % 3] = std::min(bmn[q % 3], sc->coords[q]); bmx[q % 3] = std::max(bmx[q % 3], sc->coords[q]); }
+    float centre[3];
+    double diag2 = 0;
+    for (int q = 0; q < 3; q++) { centre[q] = 0.5f * bmn[q] + 0.5f * bmx[q]; diag2 += ((double)bmx[q] - bmn[q]) * ((double)bmx[q] - bmn[q]); ctx->bbox_min[q] = bmn[q]; ctx->bbox_max[q] = bmx[q]; }
+    const float two_rs = std::nextafter((float)std::sqrt(diag2), INFINITY) * 1.0001f;    // >= 2 x half-diagonal, also after the centre's rounding
+    const float m_cap = 3.0f * two_rs;                                                // rays from within |o - centre|_1 <= 4 Rs are prunable
+    // classes: up to PTX_MAX_CLS plane normals, each time the normal of the unclassified triangle with the largest c_o
+    // among those that may be class members and gain from it; members = the triangles within delta of +- that normal
+    std::vector<TriCoef> slot_coef(T);
+    V3 cls[PTX_MAX_CLS];
+    int n_cls = 0;
+    {
+        std::vector<double> nx(T), ny(T), nz(T);
+        std::vector<float> co(T), cc(T);
+        std::vector<uint8_t> open(T, 0);
+        for (uint32_t k = 0; k < T; k++) {
+            const float4 e1 = tris[3 * (size_t)k + 1], e2 = tris[3 * (size_t)k + 2];
+            const double l1 = std::sqrt((double)e1.x * e1.x + (double)e1.y * e1.y + (double)e1.z * e1.z), l2 = std::sqrt((double)e2.x * e2.x + (double)e2.y * e2.y + (double)e2.z * e2.z);
+            const double gx = (double)e2.y * e1.z - (double)e1.y * e2.z, gy = (double)e2.z * e1.x - (double)e1.z * e2.x, gz = (double)e2.x * e1.y - (double)e1.x * e2.y;
+            const double a2 = std::sqrt(gx * gx + gy * gy + gz * gz), E = std::max(l1, l2);
+            co[k] = coef_other_of(E, m_cap);
+            cc[k] = coef_class_of(E, a2, m_cap);
+            if (a2 > 0) { nx[k] = gx / a2; ny[k] = gy / a2; nz[k] = gz / a2; }
+            open[k] = std::isfinite(cc[k]) && cc[k] < co[k];
+            slot_coef[k] = {co[k], 0.f};
+        }
+        const double lim = 0.5 * (0.999 * (double)PTX_CLS_DELTA) * (0.999 * (double)PTX_CLS_DELTA);   // |n - sN| <= delta  <=>  1 - |n . N| <= delta^2 / 2
+        for (; n_cls < PTX_MAX_CLS; n_cls++) {
+            int64_t pick = -1;
+            for (uint32_t k = 0; k < T; k++)
+                if (open[k] && (pick < 0 || co[k] > co[pick])) pick = k;
+            if (pick < 0 || !(co[pick] > 4.0f * cc[pick])) break;                     // nothing left that gains a factor of 4
+            const double Nx = nx[pick], Ny = ny[pick], Nz = nz[pick];
+            cls[n_cls] = {(float)Nx, (float)Ny, (float)Nz};
+            const double fx = cls[n_cls].x, fy = cls[n_cls].y, fz = cls[n_cls].z;     // the float class normal is what the kernels see
+            for (uint32_t k = 0; k < T; k++)
+                if (open[k] && 1.0 - std::fabs(nx[k] * fx + ny[k] * fy + nz[k] * fz) / std::sqrt(fx * fx + fy * fy + fz * fz) <= lim) {
+                    slot_coef[k] = {0.f, cc[k]};
+                    open[k] = 0;
+                }
+        }
+    }
+    std::vector<TriCoef> leaf_coef(N, TriCoef{0.f, 0.f});                             // by node index; 0 for inner nodes
+    for (uint32_t i = 0; i < N; i++) {
+        if (sc->node_first[i] == -2 || sc->node_count[i] <= 0) continue;
+        TriCoef c = {0.f, 0.f};
+        for (int32_t q = 0; q < sc->node_count[i]; q++) {
+            const TriCoef t = slot_coef[(size_t)sc->node_first[i] + q];
+            c = {std::max(c.c_o, t.c_o), std::max(c.c_c, t.c_c)};
+        }
+        leaf_coef[i] = c;
+    }
+    {   // pipelines 0 / 1 find a leaf's packed coefficients at its first slot (the largest, should leaves share a first slot)
+        std::vector<TriCoef> at_slot(T, TriCoef{0.f, 0.f});
+        for (uint32_t i = 0; i < N; i++) {
+            if (sc->node_first[i] == -2 || sc->node_count[i] <= 0) continue;
+            TriCoef& a = at_slot[(size_t)sc->node_first[i]];
+            a = {std::max(a.c_o, leaf_coef[i].c_o), std::max(a.c_c, leaf_coef[i].c_c)};
+        }
+        for (uint32_t i = 0; i < N; i++)
+            if (sc->node_first[i] != -2 && sc->node_count[i] > 0) tris[3 * (size_t)sc->node_first[i] + 1].w = bits((int32_t)pack_coefs(at_slot[(size_t)sc->node_first[i]]));
+    }
+    {   // reference tree: cutting inner node i skips exactly the nodes (i, miss[i]): their largest coefficients go into fc
+        std::vector<float> lo(N), lc(N);
+        for (uint32_t i = 0; i < N; i++) { lo[i] = leaf_coef[i].c_o; lc[i] = leaf_coef[i].c_c; }
+        const RangeMax rmo(lo), rmc(lc);
+        for (uint32_t i = 0; i < N; i++) {
+            if (!(sc->node_first[i] == -2)) continue;                                 // leaves and empty leaves keep their fc
+            const size_t end = sc->node_miss[i] < 0 ? N : (size_t)sc->node_miss[i];
+            const TriCoef c = {rmo.query((size_t)i + 1, end), rmc.query((size_t)i + 1, end)};
+            nodes[2 * (size_t)i + 1].w = bits((int32_t)(0x80000000u | pack_coefs(c)));
+        }
+    }
     // Pair records live at index first + p, which is only collision-free when the leaves' slot ranges are disjoint (they
     // partition the inorder list in every tree classes/bvh.js builds).  Arrays that share slots between leaves are still
     // legal input: such a scene is rendered by pipeline 1, which reads the 48-B records.
@@ -796,7 +1042,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
             o[1] = make_float4(v[0][2], v[1][2], v[0][3], v[1][3]);
             o[2] = make_float4(v[0][4], v[1][4], v[0][5], v[1][5]);
             o[3] = make_float4(v[0][6], v[1][6], v[0][7], v[1][7]);
-            o[4] = make_float4(v[0][8], v[1][8], bits(cnt - 2 * q), 0.f);
+            o[4] = make_float4(v[0][8], v[1][8], bits(cnt - 2 * q), q == 0 ? bits((int32_t)pack_coefs(leaf_coef[i])) : 0.f);
         }
     }
     for (uint32_t t = 0; t < T; t++) {
@@ -820,21 +1066,39 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         light[6 * (size_t)l + 4] = aE[tri];
         light[6 * (size_t)l + 5] = make_float4(pdf, area, 0.f, 0.f);
     }
+    // the 256 largest triangles (by area, as inorder slots): what ptx_selfcheck_pruning aims its grazing rays at
+    std::vector<uint32_t> big(T);
+    {
+        std::vector<float> area(T);
+        for (uint32_t k = 0; k < T; k++) {
+            const float4 e1 = tris[3 * (size_t)k + 1], e2 = tris[3 * (size_t)k + 2];
+            const float cx = e1.y * e2.z - e2.y * e1.z, cy = e1.z * e2.x - e2.z * e1.x, cz = e1.x * e2.y - e2.x * e1.y;
+            area[k] = cx * cx + cy * cy + cz * cz;
+            big[k] = k;
+        }
+        const size_t keep = std::min<size_t>(256, T);
+        std::partial_sort(big.begin(), big.begin() + keep, big.end(), [&](uint32_t a, uint32_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); });
+        big.resize(keep);
+    }
     DScene S = {};
     int rc;
     const std::vector<float4> ref_nodes = nodes;      // {min.xyz, miss}, {max.xyz, fc}: becomes layout 8 behind the octant layouts
     repack_nodes(nodes);
     if ((rc = upload(ctx, nodes, &S.nodes)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, aN, &S.attrN)) ||
-        (rc = upload(ctx, aC, &S.attrC)) || (rc = upload(ctx, aE, &S.attrE)) || (rc = upload(ctx, light, &S.light))) {
+        (rc = upload(ctx, aC, &S.attrC)) || (rc = upload(ctx, aE, &S.attrE)) || (rc = upload(ctx, light, &S.light)) ||
+        (rc = upload(ctx, big, &ctx->d_big_slots))) {
         free_scene(ctx);
         return rc;
     }
     S.N = (int)N; S.T = (int)T; S.L = (int)L;
+    S.center = {centre[0], centre[1], centre[2]}; S.two_rs = two_rs; S.m_cap = m_cap;
+    S.n_cls = n_cls;
+    for (int j = 0; j < n_cls; j++) S.cls[j] = cls[j];
     ctx->nodes_sah = nullptr; ctx->N_sah = 0;
     {
         std::vector<float4> sah;
         int n2 = 0;
-        if (build_leaf_sah(sc, sah, &n2)) {
+        if (build_leaf_sah(sc, leaf_coef, sah, &n2)) {
             // nine layouts of nmax records each: the eight octant layouts of the leaf-SAH tree, then the reference tree
             // itself, which rays with an infinite 1/d component walk (slab_node_ref).  Shorter layouts end in records that
             // no ray enters (NaN box, miss link -1, nothing to queue), so one node count serves all nine.
@@ -856,6 +1120,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         }
     }
     ctx->S = S;
+    ctx->n_big_slots = (uint32_t)big.size();
     ctx->pool_ok = disjoint;
     ctx->have_scene = true;
     ctx->prim_valid = false;
@@ -912,6 +1177,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     PTX_MULTI(ctx, multi_set_option(ctx, key, value));
     const std::string k(key);
     if (k == "traversal" && value >= 0 && value <= 3) { ctx->opt_traversal = (int)value; ctx->prim_valid = false; }
+    else if (k == "prune" && (value == 1 || value == 2)) { ctx->opt_prune = (int)value; ctx->prim_valid = false; }
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;
@@ -927,10 +1193,9 @@ static int ensure_primary(ptx_ctx* ctx, float4* d_dirs) {
     if (!ctx->have_scene || !ctx->have_params) return fail(ctx, PTX_ERR_STATE, "scene and params must be set first");
     if (ctx->prim_valid && !d_dirs) return PTX_OK;
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
-    if (opt_prune(ctx))
-        hipLaunchKernelGGL(k_primary<true>, dim3(tiles), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
-    else
-        hipLaunchKernelGGL(k_primary<false>, dim3(tiles), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
+    // primary rays are always traced WITHOUT pruning (2 M rays once per camera: 0.3 ms): the per-pixel primary-hit cache, and
+    // with it every primary hit of every frame, is the unpruned closest hit whatever option "prune" says
+    hipLaunchKernelGGL(k_primary<0>, dim3(tiles), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
     HIP_TRY(ctx, hipGetLastError());
     ctx->prim_valid = true;
     return PTX_OK;
@@ -960,7 +1225,7 @@ struct RenderBufs {
     uint32_t* task_counter;   // pipeline 2: next undrawn task of the running launch
 };
 
-template <bool PRUNE, bool MEMO, bool COUNT>
+template <int PRUNE, bool MEMO, bool COUNT>
 static hipError_t launch_render(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
     hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
@@ -968,7 +1233,7 @@ static hipError_t launch_render(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf)
     return hipGetLastError();
 }
 
-template <bool PRUNE, bool MEMO, bool COUNT>
+template <int PRUNE, bool MEMO, bool COUNT>
 static hipError_t launch_render_wave(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
     const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32: render_frames_impl caps the batch
@@ -979,12 +1244,12 @@ static hipError_t launch_render_wave(ptx_ctx* ctx, const RenderBufs& rb, uint32_
     return hipGetLastError();
 }
 
-template <bool PRUNE, bool MEMO, bool COUNT>
+template <int PRUNE, bool MEMO, bool COUNT>
 static hipError_t launch_render_pool(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
     const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32 - 2^28: render_frames_impl caps the batch
     const uint32_t chunk = (uint32_t)ctx->opt_pool_chunk;
-    uint64_t& resident = ctx->pool_resident[(PRUNE ? 4 : 0) | (MEMO ? 2 : 0) | (COUNT ? 1 : 0)];   // waves one residency of the chip holds
+    uint64_t& resident = ctx->pool_resident[PRUNE * 4 + (MEMO ? 2 : 0) + (COUNT ? 1 : 0)];   // waves one residency of the chip holds
     if (resident == 0) {
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
@@ -1001,18 +1266,22 @@ static hipError_t launch_render_pool(ptx_ctx* ctx, const RenderBufs& rb, uint32_
 
 // the path-tracing kernel of the selected pipeline / traversal / memo / count options over one batch
 static hipError_t launch_path_tracer(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
-    const int sel = (opt_prune(ctx) ? 4 : 0) | (ctx->opt_memo ? 2 : 0) | (ctx->opt_count ? 1 : 0);
+    const int sel = prune_mode(ctx) * 4 + (ctx->opt_memo ? 2 : 0) + (ctx->opt_count ? 1 : 0);
     const int pipeline = (ctx->opt_pipeline == 2 && !ctx->pool_ok) ? 1 : ctx->opt_pipeline;
 #define PTX_SEL(fn)                                                   \
     switch (sel) {                                                    \
-        case 0: return fn<false, false, false>(ctx, rb, nf);          \
-        case 1: return fn<false, false, true>(ctx, rb, nf);           \
-        case 2: return fn<false, true, false>(ctx, rb, nf);           \
-        case 3: return fn<false, true, true>(ctx, rb, nf);            \
-        case 4: return fn<true, false, false>(ctx, rb, nf);           \
-        case 5: return fn<true, false, true>(ctx, rb, nf);            \
-        case 6: return fn<true, true, false>(ctx, rb, nf);            \
-        default: return fn<true, true, true>(ctx, rb, nf);            \
+        case 0: return fn<0, false, false>(ctx, rb, nf);              \
+        case 1: return fn<0, false, true>(ctx, rb, nf);               \
+        case 2: return fn<0, true, false>(ctx, rb, nf);               \
+        case 3: return fn<0, true, true>(ctx, rb, nf);                \
+        case 4: return fn<1, false, false>(ctx, rb, nf);              \
+        case 5: return fn<1, false, true>(ctx, rb, nf);               \
+        case 6: return fn<1, true, false>(ctx, rb, nf);               \
+        case 7: return fn<1, true, true>(ctx, rb, nf);                \
+        case 8: return fn<2, false, false>(ctx, rb, nf);              \
+        case 9: return fn<2, false, true>(ctx, rb, nf);               \
+        case 10: return fn<2, true, false>(ctx, rb, nf);              \
+        default: return fn<2, true, true>(ctx, rb, nf);               \
     }
     if (pipeline == 2) { PTX_SEL(launch_render_pool) }
     if (pipeline == 1) { PTX_SEL(launch_render_wave) }
@@ -1266,19 +1535,64 @@ extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, u
     if (e == hipSuccess) {
         const uint32_t blocks = (n + 63) / 64;
         const bool pairs = ctx->opt_pipeline == 2 && ctx->pool_ok;      // the arithmetic of the renderer that is selected
-        if (opt_prune(ctx)) {
-            if (pairs) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
-            else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
-        } else {
-            if (pairs) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters);
+#define PTX_TRACE(PR, PA) hipLaunchKernelGGL((k_trace<PR, PA>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), d_o, d_d, n, d_t, d_tri, ctx->d_counters)
+        switch (prune_mode(ctx) * 2 + (pairs ? 1 : 0)) {
+            case 0: PTX_TRACE(0, false); break;
+            case 1: PTX_TRACE(0, true); break;
+            case 2: PTX_TRACE(1, false); break;
+            case 3: PTX_TRACE(1, true); break;
+            case 4: PTX_TRACE(2, false); break;
+            default: PTX_TRACE(2, true); break;
         }
+#undef PTX_TRACE
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tri_id, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_trace_closest: ") + hipGetErrorString(e));
+    return PTX_OK;
+}
+
+extern "C" int ptx_selfcheck_pruning(ptx_ctx* ctx, uint32_t family, uint64_t n_rays, uint32_t seed, ptx_selfcheck_result* out) {
+    if (!ctx || !out) return PTX_ERR_INVALID;
+    PTX_MULTI(ctx, ptx_selfcheck_pruning(ctx->subs[0], family, n_rays, seed, out));
+    if (!ctx->have_scene) return fail(ctx, PTX_ERR_STATE, "ptx_selfcheck_pruning: ptx_upload_scene first");
+    if (family > 7) return fail(ctx, PTX_ERR_INVALID, "ptx_selfcheck_pruning: family must be 0 .. 7");
+    if (n_rays == 0 || n_rays > (1ull << 37)) return fail(ctx, PTX_ERR_INVALID, "ptx_selfcheck_pruning: n_rays must be in 1 .. 2^37");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_stage(ctx, sizeof(CheckOut));
+    if (rc) return rc;
+    CheckOut* d_out = (CheckOut*)ctx->d_stage;
+    CheckOut h = {};
+    for (int q = 0; q < 16; q++) h.first_tri[q][0] = h.first_tri[q][1] = -2;
+    HIP_TRY(ctx, hipMemcpy(d_out, &h, sizeof h, hipMemcpyHostToDevice));
+    CheckArgs A = {};
+    A.n = n_rays; A.seed = seed; A.family = family; A.n_big = ctx->n_big_slots; A.big = ctx->d_big_slots;
+    A.bmin = {ctx->bbox_min[0], ctx->bbox_min[1], ctx->bbox_min[2]};
+    A.bmax = {ctx->bbox_max[0], ctx->bbox_max[1], ctx->bbox_max[2]};
+    const unsigned long long blocks = (n_rays + 63) / 64;
+    const bool pairs = ctx->opt_pipeline == 2 && ctx->pool_ok;      // the arithmetic of the renderer that is selected
+    // grid.x is 32 bits wide: launches of at most 2^30 blocks, each with its own seed offset
+    unsigned long long done = 0;
+    while (done < blocks) {
+        const unsigned long long nb = std::min<unsigned long long>(blocks - done, 1ull << 30);
+        CheckArgs B = A;
+        B.n = std::min<unsigned long long>(n_rays - done * 64ull, nb * 64ull);
+        B.seed = seed + (uint32_t)(done >> 30) * 0x632BE5ABu;
+        const bool heuristic = ctx->opt_prune == 2;                 // the pruning rule that option "prune" selects
+        if (pairs && heuristic) hipLaunchKernelGGL((k_selfcheck<2, true>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
+        else if (pairs) hipLaunchKernelGGL((k_selfcheck<1, true>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
+        else if (heuristic) hipLaunchKernelGGL((k_selfcheck<2, false>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
+        else hipLaunchKernelGGL((k_selfcheck<1, false>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
+        HIP_TRY(ctx, hipGetLastError());
+        done += nb;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(&h, d_out, sizeof h, hipMemcpyDeviceToHost));
+    out->rays = h.rays; out->hits = h.hits; out->mismatches = h.mismatches;
+    std::memcpy(out->first, h.first, sizeof h.first);
+    std::memcpy(out->first_tri, h.first_tri, sizeof h.first_tri);
     return PTX_OK;
 }
 

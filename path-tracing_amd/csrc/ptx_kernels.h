@@ -2,14 +2,16 @@
 //
 // HBM layout (replaces the eleven RGB32F data textures of main.js:272-282; DESIGN.md "Data layout"):
 //   nodes[2N] float4: [2i]   = { min.x, min.y, max.x, max.y }                            (one 32-B record per node; the
-//                     [2i+1] = { min.z, max.z, bits(miss link), bits(leaf ? first | count << 24 : -2) }   pairs feed v_pk_*_f32)
+//                     [2i+1] = { min.z, max.z, bits(miss link), fc }                      pairs feed v_pk_*_f32)
+//                     fc >= 0: leaf, first | count << 24.  fc < 0: inner node (or empty leaf): sign bit | the node's two
+//                     position-error coefficients for provable pruning as 15 + 16 bit floats (prune_coefs below); -2 = none (NaN)
 //   tris[3T]  float4: [3k]   = { v0.xyz, bits(original triangle index) }  -- indexed by INORDER SLOT k, so a
-//                     [3k+1] = { (v1 - v0).xyz, 0 }                           leaf's triangles are contiguous
+//                     [3k+1] = { (v1 - v0).xyz, packed coefs of the leaf at its first slot }   leaf's triangles are contiguous
 //                     [3k+2] = { (v2 - v0).xyz, 0 }                           (one 48-B record per triangle)
 //   pairs[5T] float4: pair p of the leaf that starts at slot `first` is record first + p (80 B) and holds slots
 //                     first + 2p (A) and first + 2p + 1 (B, zeros when the leaf's count is odd), component-interleaved:
 //                     {v0x A,B, v0y A,B} {v0z A,B, e1x A,B} {e1y A,B, e1z A,B} {e2x A,B, e2y A,B}
-//                     {e2z A,B, bits(triangles of the leaf from this pair on), 0}        (pipeline 2 only)
+//                     {e2z A,B, bits(triangles of the leaf from this pair on), packed coefs of the leaf (first pair only)}   (pipeline 2 only)
 //   attrN/attrC/attrE[T] float4 { normal | color | emission } by ORIGINAL triangle index
 //   light[L]  6 x float4 { v0, v1, v2, normal, emission, {1/(L*area),0,0,0} }
 // One node visit = 32 B, one triangle test = 48 B, attributes (48 B) only for the winning hit.
@@ -17,6 +19,10 @@
 #include "ptx_device.h"
 
 namespace ptx {
+
+#define PTX_MAX_CLS 8
+#define PTX_CLS_DELTA 2.0e-3f   // a triangle belongs to a class when its unit normal is within this distance of +- the class normal
+#define PTX_CLS_WCAP 512.0f     // the class bound is derived for w_ray <= this (rays steeper than 1/512 to every class plane)
 
 struct DScene {
     const float4* nodes;   // 2 float4 per node
@@ -30,6 +36,10 @@ struct DScene {
     uint32_t oct_stride;   // bytes between the 8 direction-octant layouts of `nodes` (0: a single layout)
     uint32_t ref_base;     // byte offset in `nodes` of the reference tree itself (layout 8 behind the octant layouts; 0 when
                            // `nodes` IS the reference tree): rays with an infinite 1/d component walk it (slab_node_ref)
+    V3 center;             // centre of the scene's bounding box                         } provable pruning: ray_kappa()
+    float two_rs, m_cap;   // twice its half-diagonal; largest M_ray the coefficients hold for }
+    int n_cls;             // dominant plane normals of the scene's large flat triangles ("classes", unit vectors)
+    V3 cls[PTX_MAX_CLS];
 };
 
 struct DParams {
@@ -90,10 +100,67 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
     }
 }
 
-// Margin of the best-t pruning (option "traversal" = 1): a node is skipped only when its slab entry
-// distance exceeds best_t * (1 + PRUNE_REL) + PRUNE_ABS.  See DESIGN.md "Pruning and exactness".
+// ---- best-t pruning (option "traversal" bit 0).  The reference never prunes (glsl:207-249), so a node may only be skipped
+// when NO triangle beneath it can produce a computed t below the best one found so far.  Template parameter PRUNE:
+//   0  no pruning
+//   1  PROVABLE pruning (default; DESIGN.md "Pruning and exactness").  For a hit the triangle test accepts, the point
+//      o + t_computed * d lies within rho of the triangle, hence of every box around it, where (rounding-error analysis of
+//      glsl:150-173; host: prune_coefs)
+//          rho <= c_o * M_ray                      for ANY triangle: the accepted determinant is >= 1e-4 in magnitude (glsl:156)
+//          rho <= c_c * M_ray * w_ray              for a triangle of a CLASS (its normal within PTX_CLS_DELTA of one of the
+//                                                  scene's n_cls dominant plane normals N_j): there the determinant is
+//                                                  >= 2 * area * (|d . N_j| - delta), so w_ray = max_j 1 / (|d . N_j| - delta)
+//      with c_o, c_c depending only on the triangle's edges and M_ray = |o - centre|_1 + 2 Rs bounding the distances involved.
+//      A point within rho of a box is inside the box grown by rho, which the ray enters no later than (slab entry of the
+//      box) - rho * max|1/d_k|.  So with kappa = M_ray * max|1/d_k| and kappa2 = kappa * w_ray (ray_kappa, once per ray), a
+//      node whose entry distance tn satisfies
+//          tn - (c_o(node) * kappa + c_c(node) * kappa2)  >  best * (1 + 2^-16)
+//      cannot hold a computed t <= best, and skipping it cannot change the (t, slot) minimum.  c_o(node) / c_c(node) are the
+//      largest coefficients beneath the node (every triangle counts in exactly one of the two): inner nodes carry them in
+//      fc (see the layout above), leaves in their first triangle / pair record.  Rays with an infinite 1/d component, rays
+//      that are not unit length and rays from far outside the scene get kappa = inf and are never pruned.
+//   2  heuristic margin  tn > best * (1 + 1e-3) + 1e-3  (option "prune" = 2): faster, but NOT exact -- rays that graze a
+//      large triangle can lose it (ptx_selfcheck_pruning finds such rays); for previews.
 #define PTX_PRUNE_REL 0.001f
 #define PTX_PRUNE_ABS 0.001f
+#define PTX_PRUNE_SAFE_REL 1.52587890625e-05f   // 2^-16: covers the three roundings of a computed slab entry distance
+
+template <int PRUNE>
+__device__ __forceinline__ float prune_limit(float best) {
+    return PRUNE == 2 ? best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS : best * (1.0f + PTX_PRUNE_SAFE_REL);
+}
+// the two coefficients of a node, packed by the host (pack_coefs): [sign][c_o: 8-bit exponent, 7-bit mantissa][c_c: 0, 8, 7],
+// both rounded up
+__device__ __forceinline__ float coef_other(uint32_t packed) { return __uint_as_float(packed & 0x7FFF0000u); }
+__device__ __forceinline__ float coef_class(uint32_t packed) { return __uint_as_float(packed << 16); }
+struct Kappa { float k, k2; };
+// is a node (entry distance tn, packed coefficients) out of reach of the ray (limit from prune_limit, kappa from ray_kappa)?
+// NaN / inf operands (coefficients of an empty leaf, kappa of an unprunable ray) make the comparison false: not pruned.
+template <int PRUNE>
+__device__ __forceinline__ bool prune_far(float tn, float limit, uint32_t packed, Kappa kap) {
+    return PRUNE == 2 ? tn > limit : (tn - (coef_other(packed) * kap.k + coef_class(packed) * kap.k2)) > limit;
+}
+// kappa and kappa2 of a ray, a hair above their exact values (v_rcp_f32 is good to 1 ulp); inf when the bound does not apply
+__device__ __forceinline__ Kappa ray_kappa(const DScene& S, V3 o, V3 d) {
+    const float m = ((fabsf(o.x - S.center.x) + fabsf(o.y - S.center.y)) + fabsf(o.z - S.center.z)) + S.two_rs;
+    const float mind = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float dd = dot(d, d);
+    const bool ok = fabsf(dd - 1.0f) <= 1.0e-3f && m <= S.m_cap;          // false for NaN
+    float minc = 1.0f;                                                     // min_j |d . N_j| (1: no classes, w = 1 / (1 - delta'))
+    for (int j = 0; j < S.n_cls; j++) minc = fminf(minc, fabsf(dot(d, S.cls[j])));
+    const float den = minc - (1.002f * PTX_CLS_DELTA + 1.0e-5f);          // also covers |d| up to 1.0005 and the dot's rounding
+    Kappa r;
+    r.k = ok ? (m * __builtin_amdgcn_rcpf(mind)) * 1.001f : __builtin_inff();   // mind = 0 -> inf
+    r.k2 = den >= (1.0f / PTX_CLS_WCAP) ? (r.k * __builtin_amdgcn_rcpf(den)) * 1.001f : __builtin_inff();   // w_ray <= WCAP, else unprunable
+    return r;
+}
+// kappa pair in one 32-bit word (LDS of pipeline 2): two 16-bit floats, rounded up (inf stays inf, NaN stays NaN)
+__device__ __forceinline__ uint32_t pack_kappa(Kappa k) {
+    const uint32_t a = __float_as_uint(k.k), b = __float_as_uint(k.k2);
+    const uint32_t ha = (a >> 16) + ((a & 0xFFFFu) ? 1u : 0u), hb = (b >> 16) + ((b & 0xFFFFu) ? 1u : 0u);
+    return (ha << 16) | (hb & 0xFFFFu);
+}
+__device__ __forceinline__ Kappa unpack_kappa(uint32_t w) { Kappa k; k.k = __uint_as_float(w & 0xFFFF0000u); k.k2 = __uint_as_float(w << 16); return k; }
 
 // 32-bit byte offsets from a uniform base: lets the compiler use the SGPR-base + VGPR-offset addressing form.
 __device__ __forceinline__ float4 ld16(const float4* base, uint32_t byte_off) {
@@ -114,9 +181,11 @@ __device__ __forceinline__ uint32_t octant(V3 d) { return (d.x < 0.0f ? 1u : 0u)
 // glsl:207-249: closest hit by the stackless threaded traversal (hit -> i+1, miss -> missLink).
 // Triangles are still tested in increasing inorder slot, and strict '<' keeps the first candidate among equal t
 // (the reference's tie rule).  PRUNE adds the conservative best-t cut; COUNT adds node/triangle counters.
-template <bool PRUNE, bool COUNT>
+template <int PRUNE, bool COUNT>
 __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& out_t, int& out_tri, LocalCnt& c) {
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    Kappa kappa = {0.f, 0.f};
+    if (PRUNE == 1) kappa = ray_kappa(S, o, d);
     float best = 1.0e38f;
     int best_tri = -1;
     uint32_t best_k = 0xFFFFFFFFu;        // inorder slot of the winner: ties on t go to the smaller slot (reference order)
@@ -127,6 +196,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
     const uint32_t nbase = deg ? S.ref_base : octant(d) * S.oct_stride;
     do {
         int pend[PTX_LEAF_BATCH];
+        float pend_tn[PTX_LEAF_BATCH];
         int n = 0;
         uint32_t it_walk = 0, it_tri = 0;
         while (n < PTX_LEAF_BATCH && i < N) {
@@ -136,12 +206,13 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
             if (COUNT) c.node_visits++;
             float tn;
             bool hit = deg ? slab_node_ref(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn);
-            if (PRUNE) hit = hit && !(tn > limit);
+            const int fc = __float_as_int(b.w);
+            if (PRUNE == 2) hit = hit && !(tn > limit);
+            if (PRUNE == 1 && fc < 0) hit = hit && !prune_far<1>(tn, limit, (uint32_t)fc, kappa);   // leaves: checked with their own coefficients below
             if (hit) {
-                const int fc = __float_as_int(b.w);
-                if (fc != -2) {
+                if (fc >= 0) {
 #pragma unroll
-                    for (int q = 0; q < PTX_LEAF_BATCH; q++) if (q == n) pend[q] = fc;
+                    for (int q = 0; q < PTX_LEAF_BATCH; q++) if (q == n) { pend[q] = fc; pend_tn[q] = tn; }
                     n++;
                 }
                 i++;
@@ -155,12 +226,14 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
             if (k == kend) {
                 if (j == n) break;
                 int fc = pend[0];
+                float ltn = pend_tn[0];
 #pragma unroll
-                for (int q = 1; q < PTX_LEAF_BATCH; q++) if (q == j) fc = pend[q];
+                for (int q = 1; q < PTX_LEAF_BATCH; q++) if (q == j) { fc = pend[q]; ltn = pend_tn[q]; }
                 j++;
                 k = (uint32_t)(fc & 0x00FFFFFF);
                 kend = k + (uint32_t)((fc >> 24) & 0x7F);
                 if (k == kend) continue;  // empty leaf
+                if (PRUNE == 1 && prune_far<1>(ltn, limit, __float_as_uint(ld16(S.tris, k * 48u + 16u).w), kappa)) { k = kend; continue; }
             }
             if (COUNT) it_tri++;
             const float4 v0 = ld16(S.tris, k * 48u);
@@ -172,7 +245,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
                 best = t;
                 best_k = k;
                 best_tri = __float_as_int(v0.w);
-                if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+                if (PRUNE) limit = prune_limit<PRUNE>(best);
             }
             k++;
         }
@@ -191,9 +264,11 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
 // on the octant layouts (slab_node_ordered, rays with an infinite 1/d component excepted) and two triangles per step from
 // the pair records (tri_test2).  ptx_trace_closest uses it when pipeline 2 is selected, so known-answer rays around the
 // shader's epsilons go through exactly the code the default renderer runs.
-template <bool PRUNE, bool COUNT>
+template <int PRUNE, bool COUNT>
 __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, float& out_t, int& out_tri, LocalCnt& c) {
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    Kappa kappa = {0.f, 0.f};
+    if (PRUNE == 1) kappa = ray_kappa(S, o, d);
     const bool deg = inv_degenerate(inv);
     const bool ordered = S.oct_stride != 0u && !deg;
     float best = 1.0e38f, limit = 3.0e38f;
@@ -207,15 +282,17 @@ __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, f
         if (COUNT) c.node_visits++;
         float tn;
         bool hit = ordered ? slab_node_ordered(o, inv, a, b, tn) : (deg ? slab_node_ref(o, inv, a, b, tn) : slab_node(o, inv, a, b, tn));
-        if (PRUNE) hit = hit && !(tn > limit);
+        const int fc = __float_as_int(b.w);
+        if (PRUNE == 2) hit = hit && !(tn > limit);
+        if (PRUNE == 1 && fc < 0) hit = hit && !prune_far<1>(tn, limit, (uint32_t)fc, kappa);
         if (!hit) { i = (uint32_t)__float_as_int(b.z); continue; }
         i++;
-        const int fc = __float_as_int(b.w);
         if (fc < 0) continue;                                  // inner node (or empty leaf)
         uint32_t k = (uint32_t)fc & 0x00FFFFFFu, pbyte = k * 80u;
-        for (;;) {
+        for (bool first_pair = true;; first_pair = false) {
             const float4 r0 = ld16(S.pairs, pbyte), r1 = ld16(S.pairs, pbyte + 16u), r2 = ld16(S.pairs, pbyte + 32u),
                          r3 = ld16(S.pairs, pbyte + 48u), r4 = ld16(S.pairs, pbyte + 64u);
+            if (PRUNE == 1 && first_pair && prune_far<1>(tn, limit, __float_as_uint(r4.w), kappa)) break;   // the leaf's own coefficients
             const int rem = __float_as_int(r4.z);
             bool hA, hB;
             float tA, tB;
@@ -226,7 +303,7 @@ __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, f
             if (rem <= 2) break;
             k += 2u; pbyte += 80u;
         }
-        if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+        if (PRUNE) limit = prune_limit<PRUNE>(best);
     }
     out_t = best;
     out_tri = best < 1.0e38f ? __float_as_int(ld16(S.tris, best_k * 48u).w) : -1;

@@ -8,8 +8,9 @@
 // (t bits << 32 | inorder slot) with one LDS min -- the lexicographic (t, slot) minimum the reference's strict '<' in
 // increasing slot order produces.  So TRI phases run with every lane busy whenever the wave has 64 leaves pending, no
 // matter how unevenly the rays produced them, and the walk never stalls on a full per-lane queue.
-// With PRUNE an item is dropped when its leaf's entry distance is already behind the owner's best hit by the time it
-// is dequeued (same conservative margin as the node test; front-to-back order makes this frequent).
+// With PRUNE an item is dropped when its leaf is out of reach of the owner's best hit by the time it is dequeued
+// (prune_far, ptx_kernels.h: provably for PRUNE = 1, by the heuristic margin for PRUNE = 2; front-to-back order makes this
+// frequent).  Inner nodes are cut in the WALK phase by the same rule with the coefficient stored in the node.
 // A ray is finished when its walk has ended and the queue head has passed its newest item (items are consumed in order).
 #pragma once
 #include "ptx_wave.h"
@@ -44,7 +45,7 @@ namespace ptx {
 
 #define PTX_POOL_KEY_NONE ((unsigned long long)0x7e967699u << 32 | 0xFFFFFFFFull)   // bits(1.0e38f) << 32 | 0xFFFFFFFF: "no hit yet"
 
-template <bool PRUNE, bool MEMO, bool COUNT>
+template <int PRUNE, bool MEMO, bool COUNT>
 __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
                                                     const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
                                                     float4* __restrict__ fb, uint32_t n_frames, uint32_t chunk,
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     __shared__ float lds[PW_C_SAMPLES * 64];         // path state only (25 words per lane); work counters live in scalar registers
     __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
     __shared__ uint2 queue[PTX_POOL_QCAP];
+    __shared__ uint32_t kap[64];                     // PRUNE = 1: packed kappa pair of the lane's ray (ray_kappa), read by whoever tests its leaves
     const uint32_t lane = threadIdx.x;
     const LdsLane L{lds + lane};
     const uint32_t npix = P.W * P.H;
@@ -104,7 +106,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
         // TRI phases are load-latency bound (five 16-B loads, then one burst of packed math): their instructions go first
         if (phase == 1) __builtin_amdgcn_s_setprio(PTX_POOL_TRI_PRIO); else __builtin_amdgcn_s_setprio(0);
         if (phase == 0) {
-            if (PRUNE) limit = __uint_as_float((uint32_t)(keys[lane] >> 32)) * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+            if (PRUNE) limit = prune_limit<PRUNE>(__uint_as_float((uint32_t)(keys[lane] >> 32)));
+            Kappa kappa = {0.f, 0.f};
+            if (PRUNE == 1) kappa = unpack_kappa(kap[lane]);
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
             const bool ordered = S.oct_stride != 0u && __ballot(walking && (flags & F_INF)) == 0ull;
             auto walk = [&](auto MODE) {
@@ -130,7 +134,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                                         : (decltype(MODE)::value == 1 ? slab_node_ref(ro, inv, a, b, tn)
                                         : ((flags & F_INF) ? slab_node_ref(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn)));
                         bool hit = hit0;
-                        if (PRUNE) hit = hit && !(tn > limit);       // a NaN or partial tn is still a lower bound of the entry distance
+                        // a NaN or partial tn is still a lower bound of the entry distance
+                        if (PRUNE == 2) hit = hit && !(tn > limit);
+                        if (PRUNE == 1) hit = hit && !(fc < 0 && prune_far<1>(tn, limit, (uint32_t)fc, kappa));   // leaves: at dequeue, with their own coefficients
                         push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
                         item = (uint32_t)fc;
                         i = hit ? i + 1u : (uint32_t)miss;
@@ -170,7 +176,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             bool go = has;
             if (PRUNE) {
                 const float b = __uint_as_float((uint32_t)(keys[owner] >> 32));
-                go = go && !(__uint_as_float(it.y) > b * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS);
+                Kappa ok = {0.f, 0.f};
+                if (PRUNE == 1) ok = unpack_kappa(kap[owner]);
+                go = go && !prune_far<PRUNE>(__uint_as_float(it.y), prune_limit<PRUNE>(b), __float_as_uint(r4.w), ok);   // r4.w: the leaf's packed coefficients
             }
             float bt = 1.0e38f;
             uint32_t bk = 0xFFFFFFFFu;
@@ -297,6 +305,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                 keys[lane] = PTX_POOL_KEY_NONE;
+                if (PRUNE == 1) kap[lane] = pack_kappa(ray_kappa(S, ro, rd));
                 limit = 3.0e38f;
                 i = 0;
                 lastpos = head;

@@ -201,7 +201,7 @@ __device__ __forceinline__ int shade_step(const DScene& S, const DParams& P, PT&
 }
 
 // One (pixel, frame) task, one lane, rays traced one after the other (pipeline 0).
-template <bool PRUNE, bool MEMO, bool COUNT>
+template <int PRUNE, bool MEMO, bool COUNT>
 __device__ __forceinline__ V3 render_pixel_frame(const DScene& S, const DParams& P, uint32_t px, uint32_t py, int32_t timestamp,
                                                  float prim_t, int prim_tri, LocalCnt& c) {
     Path p;

@@ -13,7 +13,8 @@
 // Each iteration the wave VOTES (ballot + popcount) which phase to run, and only the lanes that have that kind of
 // work execute it.  Lanes never wait for another lane's ray, leaf or path; they only wait for the vote.
 // Order of triangle tests per ray is still increasing inorder slot, so strict '<' keeps the reference's tie rule.
-// PRUNE uses the best t known when a node is visited (older or equal to the reference order's) -> conservative.
+// PRUNE uses the best t known when a node is visited (older or equal to the reference order's); PRUNE = 1 (provable,
+// ptx_kernels.h) cuts inner nodes only here, PRUNE = 2 (heuristic margin) cuts leaves as well.
 #pragma once
 #include "ptx_render.h"
 
@@ -106,7 +107,7 @@ struct PathLds {
 
 enum { F_ALIVE = 1, F_TASK = 2, F_TRAV = 4, F_CACHED = 8, F_INF = 16 /* 1/d has an infinite or NaN component */ };
 
-template <bool PRUNE, bool MEMO, bool COUNT>
+template <int PRUNE, bool MEMO, bool COUNT>
 __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S, DParams P, const int32_t* __restrict__ timestamps,
                                                     const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
                                                     float4* __restrict__ fb, uint32_t n_frames, uint32_t tasks_per_wave,
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
     int flags = F_ALIVE;
     V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f), inv = mk(0.f, 0.f, 0.f);
     float best = 1.0e38f, limit = 3.0e38f;
+    Kappa kappa = {0.f, 0.f};
     int best_tri = -1;
     uint32_t best_k = 0xFFFFFFFFu;
     uint32_t i = 0xFFFFFFFFu, nbase = 0;
@@ -170,9 +172,10 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                     float tn;
                     const bool deg = (flags & F_INF) != 0;       // reference tree, SwiftShader's NaN rule
                     bool hit = deg ? slab_node_ref(ro, inv, a, b, tn) : slab_node(ro, inv, a, b, tn);
-                    if (PRUNE) hit = hit && !(tn > limit);
                     const int fc = __float_as_int(b.w);
-                    const bool push = hit && fc != -2;
+                    if (PRUNE == 2) hit = hit && !(tn > limit);
+                    if (PRUNE == 1) hit = hit && !(fc < 0 && prune_far<1>(tn, limit, (uint32_t)fc, kappa));
+                    const bool push = hit && fc >= 0;
 #pragma unroll
                     for (int e = 0; e < PTX_WAVE_QUEUE; e++) if (push && e == nq) q[e] = fc;
                     nq += push ? 1 : 0;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                             best = t;
                             best_k = k + u;
                             best_tri = __float_as_int(tv0[u].w);
-                            if (PRUNE) limit = best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS;
+                            if (PRUNE) limit = prune_limit<PRUNE>(best);
                         }
                     }
                 }
@@ -293,6 +296,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                 flags = deg ? (flags | F_INF) : (flags & ~F_INF);
                 nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
                 best = 1.0e38f; limit = 3.0e38f; best_tri = -1; best_k = 0xFFFFFFFFu;
+                if (PRUNE == 1) kappa = ray_kappa(S, ro, rd);
                 i = 0; nq = 0; k = 0; kend = 0;
                 flags |= F_TRAV;
                 c.rays_traced++;

@@ -22,7 +22,7 @@ def setup(ctx, ptx, name, w, h, spp=4, bounces=4, **opts):
     p = ptx.config_params(name, w, h, spp, bounces)
     ctx.upload_scene(s)
     ctx.set_params(p)
-    for k, v in {**dict(traversal=3, memo=1, count=0, frame_batch=0, pipeline=2, tasks_per_wave=128), **opts}.items():
+    for k, v in {**dict(traversal=3, prune=2, memo=1, count=0, frame_batch=0, pipeline=2, tasks_per_wave=128), **opts}.items():
         ctx.set_option(k, v)
     ctx.reset_accum()
     ctx.reset_counters()
