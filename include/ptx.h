@@ -147,6 +147,10 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 GL leaves the target's float -> 8-bit store and the texel chosen on an exact texel boundary to the
  *                 implementation: 1 uses the preferred rules (round to nearest; floor), 2 those of SwiftShader, the
  *                 implementation behind tests/golden/ref_frames, whose frames it reproduces byte for byte
+ *   "overlap"   : 1 (default) = successive ptx_render_frames calls alternate between two launch slots (stream, frame buffers,
+ *                 task counter each), so the kernel of call k + 1 fills the chip while the last, longest paths of call k
+ *                 finish; the frame-order sum is kept by events.  A loop that renders one frame per call without
+ *                 synchronising in between (main.js:400-405) then runs at the batched rate.  0 = one launch after the other
  *   "frame_batch": max frames rendered concurrently (0 = auto)
  *   "tasks_per_wave": (pixel, frame) tasks one wave of pipeline 1 works through (default 128)
  *   "pool_chunk": pipeline 2 runs one chip residency of persistent waves; each draws this many tasks at a time from a

@@ -295,9 +295,28 @@ __global__ __launch_bounds__(64) void k_selfcheck(DScene S, CheckArgs A, CheckOu
 
 // ------------------------------------------------------------------------------------------ host side
 
+// Two launch slots, used alternately by successive ptx_render_frames calls: each has its own stream, frame buffers,
+// timestamps and task counter, so the path-tracing kernel of call k + 1 starts filling the chip while the last, longest paths
+// of call k are still finishing (one-frame-per-call loops like main.js:400-405 otherwise pay that drain on every frame).
+// The frame-order sum into the shared accumulation buffer is kept by events: a call's k_accumulate waits for the other slot's
+// last one.
+struct LaunchSlot {
+    hipStream_t stream = nullptr;
+    float4* d_fb = nullptr;                     // batch frame buffers
+    size_t fb_frames = 0;
+    int32_t* d_ts = nullptr;
+    size_t ts_cap = 0;
+    uint32_t* d_task_counter = nullptr;         // pipeline 2: next undrawn (pixel, frame) task of the running launch
+    hipEvent_t ev_done = nullptr;               // recorded behind the slot's last accumulate / blend
+    bool busy = false;                          // ev_done has been recorded since the last full synchronisation
+};
+
 struct ptx_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;               // = slot[0].stream: everything that is not a render launch runs here
+    LaunchSlot slot[2];
+    int next_slot = 0;
+    int opt_overlap = 1;                        // option "overlap": 0 = every call on slot 0 (strictly one launch after the other)
     std::string err;
 
     // scene
@@ -321,11 +340,6 @@ struct ptx_ctx {
     int compat_cur = 0;                         // which of the two holds the newest blend
     uint32_t frames_done = 0;
 
-    // batch frame buffers
-    float4* d_fb = nullptr;
-    size_t fb_frames = 0;
-    int32_t* d_ts = nullptr;
-    size_t ts_cap = 0;
     unsigned char* d_scratch = nullptr;         // this device's copy of g_scratch (ptx_render_frames_noalloc); not owned
     void* d_stage = nullptr;                    // grow-only staging for read-backs and the trace hook (ensure_stage)
     size_t stage_cap = 0;
@@ -346,7 +360,6 @@ struct ptx_ctx {
 
     // counters + timing
     unsigned long long* d_counters = nullptr;
-    uint32_t* d_task_counter = nullptr;       // pipeline 2: next undrawn (pixel, frame) task of the running launch
     uint64_t pool_resident[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // pipeline 2: grid size per kernel variant (queried once)
     bool pool_ok = true;                       // pipeline 2 needs disjoint leaf ranges (pair records are addressed by first slot)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
@@ -395,6 +408,14 @@ static inline DScene scene_view(const ptx_ctx* c) {
 static int fail(ptx_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
+}
+
+// both launch slots idle (device current)
+static hipError_t sync_all(ptx_ctx* ctx) {
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2; k++)
+        if (ctx->slot[k].stream) { const hipError_t ek = hipStreamSynchronize(ctx->slot[k].stream); if (e == hipSuccess) e = ek; ctx->slot[k].busy = false; }
+    return e;
 }
 
 // ---- multi-device contexts route every entry point to their subs (definitions at the end of this file)
@@ -452,15 +473,22 @@ extern "C" ptx_ctx* ptx_create(const int* device_ids, int n_devices) {
     }
     ptx_ctx* ctx = new ptx_ctx();
     ctx->device = device_ids[0];
-    if ((e = hipSetDevice(ctx->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+    if ((e = hipSetDevice(ctx->device)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->slot[0].stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->slot[1].stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->slot[0].ev_done, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->slot[1].ev_done, hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(&ctx->d_counters, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMemset(ctx->d_counters, 0, CNT_NUM * sizeof(unsigned long long))) != hipSuccess ||
-        (e = hipMalloc(&ctx->d_task_counter, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc(&ctx->slot[0].d_task_counter, sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc(&ctx->slot[1].d_task_counter, sizeof(uint32_t))) != hipSuccess ||
         (e = scratch_for_device(ctx->device, &ctx->d_scratch)) != hipSuccess) {
         g_create_error = std::string("ptx_create: ") + hipGetErrorString(e);
+        ctx->stream = ctx->slot[0].stream;
         ptx_destroy(ctx);                  // releases whatever was created before the failing call
         return nullptr;
     }
+    ctx->stream = ctx->slot[0].stream;
     return ctx;
 }
 
@@ -476,11 +504,10 @@ static void free_params_buffers(ptx_ctx* ctx) {
     if (ctx->d_prim_tri) (void)hipFree(ctx->d_prim_tri);
     if (ctx->d_accum) (void)hipFree(ctx->d_accum);
     for (int k = 0; k < 2; k++) { if (ctx->d_compat[k]) (void)hipFree(ctx->d_compat[k]); ctx->d_compat[k] = nullptr; }
-    if (ctx->d_fb) (void)hipFree(ctx->d_fb);
+    for (LaunchSlot& sl : ctx->slot) { if (sl.d_fb) (void)hipFree(sl.d_fb); sl.d_fb = nullptr; sl.fb_frames = 0; }
     if (ctx->d_total) (void)hipFree(ctx->d_total);
     ctx->d_total = nullptr;
-    ctx->d_prim_t = nullptr; ctx->d_prim_tri = nullptr; ctx->d_accum = nullptr; ctx->d_fb = nullptr;
-    ctx->fb_frames = 0;
+    ctx->d_prim_t = nullptr; ctx->d_prim_tri = nullptr; ctx->d_accum = nullptr;
     ctx->prim_valid = false;
     ctx->have_params = false;                  // set again only once every buffer of the new size exists
 }
@@ -488,7 +515,7 @@ static void free_params_buffers(ptx_ctx* ctx) {
 // Grow-only device staging shared by the read-backs and ptx_trace_closest (one buffer, reused: no hipMalloc per call).
 static int ensure_stage(ptx_ctx* ctx, size_t bytes) {
     if (ctx->stage_cap >= bytes) return PTX_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     ctx->d_stage = nullptr; ctx->stage_cap = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_stage, bytes));
@@ -500,17 +527,20 @@ extern "C" void ptx_destroy(ptx_ctx* ctx) {
     if (!ctx) return;
     if (!ctx->subs.empty()) { multi_destroy(ctx); return; }
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)sync_all(ctx);
     comm_release(ctx);
     free_scene(ctx);
     free_params_buffers(ctx);
-    if (ctx->d_ts) (void)hipFree(ctx->d_ts);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->d_task_counter) (void)hipFree(ctx->d_task_counter);
     for (auto& pr : ctx->pending_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto ev : ctx->free_events) (void)hipEventDestroy(ev);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (LaunchSlot& sl : ctx->slot) {
+        if (sl.d_ts) (void)hipFree(sl.d_ts);
+        if (sl.d_task_counter) (void)hipFree(sl.d_task_counter);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
     delete ctx;
 }
 
@@ -917,7 +947,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         if (sc->light_tri[l] < 0 || (uint32_t)sc->light_tri[l] >= T) return fail(ctx, PTX_ERR_INVALID, "ptx_upload_scene: light_tri out of range");
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     free_scene(ctx);
 
     std::vector<float4> nodes((size_t)N * 2), tris((size_t)T * 3), pairs((size_t)T * 5), aN(T), aC(T), aE(T), light((size_t)L * 6);
@@ -1132,6 +1162,7 @@ extern "C" int ptx_reset_accum(ptx_ctx* ctx) {
     PTX_MULTI(ctx, multi_for_all(ctx, ptx_reset_accum));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_reset_accum: ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sync_all(ctx));                                  // nothing of either launch slot may still be adding to it
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_accum, 0, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), ctx->stream));
     for (int k = 0; k < 2; k++)
         if (ctx->d_compat[k]) HIP_TRY(ctx, hipMemsetAsync(ctx->d_compat[k], 0, (size_t)ctx->P.W * ctx->P.H * sizeof(uchar4), ctx->stream));
@@ -1147,7 +1178,7 @@ extern "C" int ptx_set_params(ptx_ctx* ctx, const ptx_params* p) {
     if (p->sample_count < 1) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: sample_count must be >= 1");
     if (p->max_path_length > 65535) return fail(ctx, PTX_ERR_INVALID, "ptx_set_params: max_path_length must be <= 65535");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     const bool resize = !ctx->have_params || ctx->P.W != p->width || ctx->P.H != p->height;
     DParams P = {};
     P.W = p->width; P.H = p->height;
@@ -1178,6 +1209,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     const std::string k(key);
     if (k == "traversal" && value >= 0 && value <= 3) { ctx->opt_traversal = (int)value; ctx->prim_valid = false; }
     else if (k == "prune" && (value == 1 || value == 2)) { ctx->opt_prune = (int)value; ctx->prim_valid = false; }
+    else if (k == "overlap" && (value == 0 || value == 1)) ctx->opt_overlap = (int)value;
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;
@@ -1197,6 +1229,7 @@ static int ensure_primary(ptx_ctx* ctx, float4* d_dirs) {
     // with it every primary hit of every frame, is the unpruned closest hit whatever option "prune" says
     hipLaunchKernelGGL(k_primary<0>, dim3(tiles), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
     HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // once per camera: both launch slots read the cache
     ctx->prim_valid = true;
     return PTX_OK;
 }
@@ -1223,12 +1256,14 @@ struct RenderBufs {
     float4* fb;               // nf x W*H clamp(mean) images of the batch
     const int32_t* ts;        // nf timestamps of the batch
     uint32_t* task_counter;   // pipeline 2: next undrawn task of the running launch
+    hipStream_t stream;       // the launch slot's stream
+    hipEvent_t wait_before_sum;   // the other slot's last accumulate (frame order of the sum), or nullptr
 };
 
 template <int PRUNE, bool MEMO, bool COUNT>
 static hipError_t launch_render(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
-    hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
+    hipLaunchKernelGGL((k_render<PRUNE, MEMO, COUNT>), dim3(tiles, nf), dim3(64), 0, rb.stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
                        ctx->d_prim_tri, rb.fb, ctx->d_counters);
     return hipGetLastError();
 }
@@ -1239,7 +1274,7 @@ static hipError_t launch_render_wave(ptx_ctx* ctx, const RenderBufs& rb, uint32_
     const uint64_t total = (uint64_t)tiles * 64u * nf;   // < 2^32: render_frames_impl caps the batch
     const uint32_t per_wave = (uint32_t)ctx->opt_tasks_per_wave;
     const uint32_t blocks = (uint32_t)((total + per_wave - 1) / per_wave);
-    hipLaunchKernelGGL((k_render_wave<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
+    hipLaunchKernelGGL((k_render_wave<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, rb.stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
                        ctx->d_prim_tri, rb.fb, nf, per_wave, ctx->d_counters);
     return hipGetLastError();
 }
@@ -1257,9 +1292,9 @@ static hipError_t launch_render_pool(ptx_ctx* ctx, const RenderBufs& rb, uint32_
         resident = (uint64_t)per_cu * (uint64_t)cus;   // any value is correct (waves draw work until none is left); this one fills the chip
     }
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident, (total + chunk - 1) / chunk);
-    hipError_t e = hipMemsetAsync(rb.task_counter, 0, sizeof(uint32_t), ctx->stream);
+    hipError_t e = hipMemsetAsync(rb.task_counter, 0, sizeof(uint32_t), rb.stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
+    hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, rb.stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
                        ctx->d_prim_tri, rb.fb, nf, chunk, rb.task_counter, ctx->d_counters);
     return hipGetLastError();
 }
@@ -1302,26 +1337,27 @@ static int render_batch(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf, uint32_
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         if (ctx->pending_events.size() >= 64) {   // a caller that never synchronises: keep the event list bounded
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, sync_all(ctx));
             drain_events(ctx);
         }
         int rc = get_event(ctx, &e0);
         if (rc == PTX_OK && (rc = get_event(ctx, &e1)) != PTX_OK) ctx->free_events.push_back(e0);
         if (rc) return rc;
-        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(e0, rb.stream));
     }
     HIP_TRY(ctx, launch_path_tracer(ctx, rb, nf));
     if (timed) {
-        HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(e1, rb.stream));
         ctx->pending_events.emplace_back(e0, e1);
     }
     ctx->kernel_launches++;
-    hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, rb.fb, (uint32_t)npix, nf);
+    if (rb.wait_before_sum) HIP_TRY(ctx, hipStreamWaitEvent(rb.stream, rb.wait_before_sum, 0));   // frames are summed in order
+    hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, rb.stream, ctx->d_accum, rb.fb, (uint32_t)npix, nf);
     HIP_TRY(ctx, hipGetLastError());
     if (ctx->opt_compat) {   // the reference's own progressive blend, one frame after the other through the 8-bit targets
         for (uint32_t f = 0; f < nf; f++) {
             const float bf = 1.0f / (float)(frame_number0 + f + 1u);        // glsl:537: 1.0 / float(frameNumber + 1)
-            hipLaunchKernelGGL(k_blend_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur],
+            hipLaunchKernelGGL(k_blend_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, rb.stream, ctx->d_compat[ctx->compat_cur],
                                rb.fb + (size_t)f * npix, ctx->d_compat[ctx->compat_cur ^ 1], ctx->P.W, ctx->P.H, ctx->P.aspect, bf, ctx->opt_compat);
             ctx->compat_cur ^= 1;
         }
@@ -1345,25 +1381,29 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
     // frames rendered concurrently: bounded by an 8 GiB frame-buffer budget (HBM is 288 GB) and 65535 grid.y
     size_t batch = ctx->opt_frame_batch > 0 ? (size_t)ctx->opt_frame_batch : std::min<size_t>(64, std::max<size_t>(1, (8ull << 30) / (npix * sizeof(float4))));
     batch = cap_batch(ctx, std::min<size_t>(batch, n_frames));
-    if (ctx->fb_frames < batch) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_fb) (void)hipFree(ctx->d_fb);
-        ctx->d_fb = nullptr; ctx->fb_frames = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_fb, batch * npix * sizeof(float4)));
-        ctx->fb_frames = batch;
+    // this call's launch slot: the two alternate, so its kernel overlaps the drain of the previous call's (LaunchSlot)
+    LaunchSlot& sl = ctx->slot[ctx->opt_overlap ? ctx->next_slot : 0];
+    LaunchSlot& other = ctx->slot[&sl == &ctx->slot[0] ? 1 : 0];
+    if (sl.fb_frames < batch) {
+        HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+        if (sl.d_fb) (void)hipFree(sl.d_fb);
+        sl.d_fb = nullptr; sl.fb_frames = 0;
+        HIP_TRY(ctx, hipMalloc(&sl.d_fb, batch * npix * sizeof(float4)));
+        sl.fb_frames = batch;
     }
-    if (ctx->ts_cap < n_frames) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_ts) (void)hipFree(ctx->d_ts);
-        ctx->d_ts = nullptr; ctx->ts_cap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->d_ts, (size_t)n_frames * sizeof(int32_t)));
-        ctx->ts_cap = n_frames;
+    if (sl.ts_cap < n_frames) {
+        HIP_TRY(ctx, hipStreamSynchronize(sl.stream));
+        if (sl.d_ts) (void)hipFree(sl.d_ts);
+        sl.d_ts = nullptr; sl.ts_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&sl.d_ts, (size_t)n_frames * sizeof(int32_t)));
+        sl.ts_cap = n_frames;
     }
     if (ctx->opt_compat)
         for (int k = 0; k < 2; k++)
             if (!ctx->d_compat[k]) {
+                HIP_TRY(ctx, sync_all(ctx));
                 HIP_TRY(ctx, hipMalloc(&ctx->d_compat[k], npix * sizeof(uchar4)));
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_compat[k], 0, npix * sizeof(uchar4), ctx->stream));
+                HIP_TRY(ctx, hipMemset(ctx->d_compat[k], 0, npix * sizeof(uchar4)));
             }
     // the timestamps travel by value in kernel arguments, 64 per launch: no copy from pageable host memory, which would make
     // the call wait for everything queued before it; the caller's array is free to go when this returns
@@ -1371,14 +1411,17 @@ extern "C" int ptx_render_frames(ptx_ctx* ctx, const int32_t* timestamps, uint32
         const uint32_t nf = std::min<uint32_t>(PTX_SCRATCH_MAX_BATCH, n_frames - f0);
         TsBlock tb = {};
         std::memcpy(tb.v, timestamps + f0, nf * sizeof(int32_t));
-        hipLaunchKernelGGL(k_store_timestamps, dim3(1), dim3(64), 0, ctx->stream, tb, ctx->d_ts + f0, nf);
+        hipLaunchKernelGGL(k_store_timestamps, dim3(1), dim3(64), 0, sl.stream, tb, sl.d_ts + f0, nf);
     }
     HIP_TRY(ctx, hipGetLastError());
     for (uint32_t f0 = 0; f0 < n_frames; f0 += (uint32_t)batch) {
         const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
-        const RenderBufs rb = {ctx->d_fb, ctx->d_ts + f0, ctx->d_task_counter};
+        const RenderBufs rb = {sl.d_fb, sl.d_ts + f0, sl.d_task_counter, sl.stream, other.busy ? other.ev_done : nullptr};
         if ((rc = render_batch(ctx, rb, nf, first_frame_number + f0, true))) return rc;
     }
+    HIP_TRY(ctx, hipEventRecord(sl.ev_done, sl.stream));
+    sl.busy = true;
+    if (ctx->opt_overlap) ctx->next_slot ^= 1;
     return PTX_OK;
 }
 
@@ -1404,7 +1447,10 @@ extern "C" int ptx_render_frames_noalloc(ptx_ctx* ctx, const int32_t* timestamps
     if (rc) return rc;
     unsigned char* const base = ctx->d_scratch;                               // the device address, never the symbol's name
     int32_t* const d_ts = (int32_t*)(base + PTX_SCRATCH_TS_OFFSET);
-    const RenderBufs rb = {(float4*)(base + PTX_SCRATCH_HEADER), d_ts, (uint32_t*)base};
+    LaunchSlot& sl = ctx->slot[0];                                            // one scratch per GPU: always slot 0, behind slot 1's work
+    LaunchSlot& other = ctx->slot[1];
+    if (other.busy) HIP_TRY(ctx, hipStreamWaitEvent(sl.stream, other.ev_done, 0));
+    const RenderBufs rb = {(float4*)(base + PTX_SCRATCH_HEADER), d_ts, (uint32_t*)base, sl.stream, nullptr};
     const size_t batch = cap_batch(ctx, std::min<size_t>(std::min<size_t>(PTX_SCRATCH_MAX_BATCH, cap / npix), n_frames));
     for (uint32_t f0 = 0; f0 < n_frames; f0 += (uint32_t)batch) {
         const uint32_t nf = (uint32_t)std::min<size_t>(batch, n_frames - f0);
@@ -1414,6 +1460,8 @@ extern "C" int ptx_render_frames_noalloc(ptx_ctx* ctx, const int32_t* timestamps
         HIP_TRY(ctx, hipGetLastError());
         if ((rc = render_batch(ctx, rb, nf, first_frame_number + f0, false))) return rc;   // untimed: creates no events
     }
+    HIP_TRY(ctx, hipEventRecord(sl.ev_done, sl.stream));
+    sl.busy = true;
     return PTX_OK;
 }
 
@@ -1421,7 +1469,7 @@ extern "C" int ptx_synchronize(ptx_ctx* ctx) {
     if (!ctx) return PTX_ERR_INVALID;
     PTX_MULTI(ctx, multi_for_all(ctx, ptx_synchronize));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     drain_events(ctx);
     return PTX_OK;
 }
@@ -1471,9 +1519,10 @@ extern "C" int ptx_read_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma, int f
     if (rc) return rc;
     uchar4* d_out = (uchar4*)ctx->d_stage;
     const float nf = (float)(ctx->frames_done ? ctx->frames_done : 1);
+    HIP_TRY(ctx, sync_all(ctx));
     hipLaunchKernelGGL(k_pack_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_accum, ctx->P.W, ctx->P.H, nf, apply_gamma, flip_y, d_out);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = sync_all(ctx);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, npix * sizeof(uchar4), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_read_rgba8: ") + hipGetErrorString(e));
     drain_events(ctx);
@@ -1490,10 +1539,11 @@ extern "C" int ptx_read_compat_rgba8(ptx_ctx* ctx, uint8_t* out, int apply_gamma
     int rc = ensure_stage(ctx, npix * sizeof(uchar4));
     if (rc) return rc;
     uchar4* d_out = (uchar4*)ctx->d_stage;
+    HIP_TRY(ctx, sync_all(ctx));
     hipLaunchKernelGGL(k_display_rgba8, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_compat[ctx->compat_cur], ctx->P.W, ctx->P.H,
                        apply_gamma, flip_y, ctx->opt_compat, d_out);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = sync_all(ctx);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, npix * sizeof(uchar4), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_read_compat_rgba8: ") + hipGetErrorString(e));
     drain_events(ctx);
@@ -1509,7 +1559,7 @@ extern "C" int ptx_write_sum_f32(ptx_ctx* ctx, const float* rgb, uint32_t frames
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
     std::vector<float4> h(npix);
     for (size_t i = 0; i < npix; i++) h[i] = make_float4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 0.f);
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     HIP_TRY(ctx, hipMemcpy(ctx->d_accum, h.data(), npix * sizeof(float4), hipMemcpyHostToDevice));
     ctx->frames_done = frames_done;
     return PTX_OK;
@@ -1547,7 +1597,7 @@ extern "C" int ptx_trace_closest(ptx_ctx* ctx, const float* o, const float* d, u
 #undef PTX_TRACE
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = sync_all(ctx);
     if (e == hipSuccess) e = hipMemcpy(t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(tri_id, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(ctx, PTX_ERR_HIP, std::string("ptx_trace_closest: ") + hipGetErrorString(e));
@@ -1588,7 +1638,7 @@ extern "C" int ptx_selfcheck_pruning(ptx_ctx* ctx, uint32_t family, uint64_t n_r
         HIP_TRY(ctx, hipGetLastError());
         done += nb;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     HIP_TRY(ctx, hipMemcpy(&h, d_out, sizeof h, hipMemcpyDeviceToHost));
     out->rays = h.rays; out->hits = h.hits; out->mismatches = h.mismatches;
     std::memcpy(out->first, h.first, sizeof h.first);
@@ -1602,7 +1652,7 @@ extern "C" int ptx_primary_hits(ptx_ctx* ctx, int32_t* tri_id, float* t) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_primary(ctx, nullptr);
     if (rc) return rc;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     const size_t npix = (size_t)ctx->P.W * ctx->P.H;
     HIP_TRY(ctx, hipMemcpy(tri_id, ctx->d_prim_tri, npix * 4, hipMemcpyDeviceToHost));
     HIP_TRY(ctx, hipMemcpy(t, ctx->d_prim_t, npix * 4, hipMemcpyDeviceToHost));
@@ -1619,7 +1669,7 @@ extern "C" int ptx_primary_dirs(ptx_ctx* ctx, float* dirs) {
     if (rc) return rc;
     float4* d_dirs = (float4*)ctx->d_stage;
     rc = ensure_primary(ctx, d_dirs);
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = sync_all(ctx);
     std::vector<float4> h(npix);
     if (rc == PTX_OK && e == hipSuccess) e = hipMemcpy(h.data(), d_dirs, npix * sizeof(float4), hipMemcpyDeviceToHost);
     if (rc) return rc;
@@ -1660,8 +1710,9 @@ extern "C" int ptx_accum_export_device(ptx_ctx* ctx, void* d_dst) {
     PTX_MULTI(ctx, multi_accum_export(ctx, d_dst));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sync_all(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(d_dst, ctx->d_accum, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     drain_events(ctx);
     return PTX_OK;
 }
@@ -1671,8 +1722,9 @@ extern "C" int ptx_accum_import_device(ptx_ctx* ctx, const void* d_src, uint32_t
     PTX_MULTI(ctx, multi_accum_import(ctx, d_src, frames_done));
     if (!ctx->have_params) return fail(ctx, PTX_ERR_STATE, "ptx_set_params first");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, sync_all(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accum, d_src, (size_t)ctx->P.W * ctx->P.H * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     ctx->frames_done = frames_done;
     return PTX_OK;
 }
@@ -1829,6 +1881,7 @@ extern "C" int ptx_allreduce(ptx_ctx* ctx, void* d_dst, uint32_t* frames_total) 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t count = (size_t)ctx->P.W * ctx->P.H * 4;
     const unsigned long long mine = ctx->frames_done;
+    HIP_TRY(ctx, sync_all(ctx));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_comm_cnt, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
     NCCL_TRY(ctx, api, api->GroupStart());
     const int r1 = api->AllReduce(ctx->d_accum, d_dst ? d_dst : (void*)ctx->d_accum, count, NCCL_FLOAT32, NCCL_SUM, (ncclComm_t)ctx->comm, ctx->stream);
@@ -1837,7 +1890,7 @@ extern "C" int ptx_allreduce(ptx_ctx* ctx, void* d_dst, uint32_t* frames_total) 
     if (r1 || r2 || r3) return fail(ctx, PTX_ERR_HIP, std::string("ncclAllReduce: ") + api->GetErrorString(r1 ? r1 : (r2 ? r2 : r3)));
     unsigned long long total = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&total, ctx->d_comm_cnt, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, sync_all(ctx));
     drain_events(ctx);
     if (!d_dst) ctx->frames_done = (uint32_t)total;
     if (frames_total) *frames_total = (uint32_t)total;
@@ -1945,10 +1998,10 @@ static int multi_reduce(ptx_ctx* m) {
         srcs.n = (int)G;
         for (size_t g = 0; g < G; g++) srcs.p[g] = m->subs[g]->d_accum;
         HIP_TRY(m, hipSetDevice(s0->device));
-        for (size_t g = 1; g < G; g++) HIP_TRY(m, hipStreamSynchronize(m->subs[g]->stream));    // their frames are in their buffers
+        for (size_t g = 1; g < G; g++) HIP_TRY(m, sync_all(m->subs[g]));    // their frames are in their buffers
         hipLaunchKernelGGL(k_sum_accums, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, s0->stream, s0->d_total, srcs, (uint32_t)npix);
         HIP_TRY(m, hipGetLastError());
-        HIP_TRY(m, hipStreamSynchronize(s0->stream));
+        HIP_TRY(m, sync_all(s0));
     } else {
         std::string err;
         const RcclApi* api = rccl_api(&err);
@@ -1971,7 +2024,7 @@ static int multi_reduce(ptx_ctx* m) {
         if (bad || end) return fail(m, PTX_ERR_HIP, std::string("ncclAllReduce (grouped): ") + (bad > 0 ? api->GetErrorString(bad) : (end ? api->GetErrorString(end) : "hipSetDevice failed")));
         for (ptx_ctx* s : m->subs) {
             HIP_TRY(m, hipSetDevice(s->device));
-            HIP_TRY(m, hipStreamSynchronize(s->stream));
+            HIP_TRY(m, sync_all(s));
         }
     }
     for (ptx_ctx* s : m->subs) drain_events(s);

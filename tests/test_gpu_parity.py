@@ -476,3 +476,33 @@ def test_full_size_properties(gpu_ctx, ptx, orc, cfg):
     _, tri_o, _ = orc.primary_hits(s, ptx.config_params(c["scene"], c["width"], c["height"])) if cfg == "C2" else (None, None, None)
     if tri_o is not None:
         assert (tri_o == tri1).all()
+
+
+@pytest.mark.parametrize("pipeline", [0, 1, 2])
+def test_overlapped_one_frame_calls_equal_one_call(gpu_ctx, ptx, orc, pipeline):
+    """Successive ptx_render_frames calls alternate between two launch slots (option "overlap"): a loop of one-frame calls that
+    never synchronises (the reference's frame loop, main.js:400-405) must leave the same bits as one call with all frames --
+    the sum stays in frame order -- also through the 8-bit compat blend, a mid-loop read-back, and the no-alloc entry point."""
+    name = "my_cornell_6"
+    s, p = setup(gpu_ctx, ptx, name, 72, 40, spp=3, bounces=4, pipeline=pipeline, compat_rgba8=2)
+    ts = ptx.scene.timestamps(9)
+    gpu_ctx.set_option("overlap", 0)
+    gpu_ctx.render_frames(ts)
+    want, want8 = gpu_ctx.read_sum(), gpu_ctx.read_compat_rgba8()
+    oracle, _ = orc.render_frames(s, p, ts)
+    assert (bits(want) == bits(oracle)).all()
+    for overlap in (1, 0):
+        gpu_ctx.set_option("overlap", overlap)
+        gpu_ctx.reset_accum()
+        for f, t in enumerate(ts):
+            if f == 6:
+                gpu_ctx.render_frames_noalloc([t], first_frame_number=f)       # slot 0 + the static scratch, behind slot 1's work
+            else:
+                gpu_ctx.render_frames([t], first_frame_number=f)
+            if f == 3:
+                assert gpu_ctx.frames_done == 4 and (bits(gpu_ctx.read_sum()) == bits(orc.render_frames(s, p, ts[:4])[0])).all()
+        assert (bits(gpu_ctx.read_sum()) == bits(want)).all() and (gpu_ctx.read_compat_rgba8() == want8).all()
+        gpu_ctx.reset_accum()
+        gpu_ctx.render_frames(ts[:5]); gpu_ctx.render_frames(ts[5:], first_frame_number=5)            # uneven calls
+        assert (bits(gpu_ctx.read_sum()) == bits(want)).all()
+    gpu_ctx.set_option("overlap", 1); gpu_ctx.set_option("compat_rgba8", 0)

@@ -20,3 +20,15 @@ for order in (0,):
         if order == 0: ref[n] = img
         else: assert (img.view(np.uint32) == ref[n].view(np.uint32)).all()
         print(f"{cfg} frames/launch={n:3d} ms/frame={dt*1000/n:.1f} total={dt*1000:.1f} ms", flush=True)
+    # a loop of one-frame calls that only synchronises at the end (the reference's frame loop, main.js:400-405, without its sleeps)
+    for overlap in (0, 1):
+        ctx.set_option("overlap", overlap)
+        ctx.reset_accum(); ctx.render_frames([999]); ctx.synchronize()
+        ctx.reset_accum()
+        n = 32
+        t0 = time.time()
+        for f in range(n):
+            ctx.render_frames([1000 + f], first_frame_number=f)
+        ctx.synchronize(); dt = time.time() - t0
+        assert (ctx.read_sum().view(np.uint32) == ref[32].view(np.uint32)).all() if 32 in ref else True
+        print(f"{cfg} {n} calls of 1 frame, overlap={overlap}: ms/frame={dt*1000/n:.1f}", flush=True)
