@@ -11,12 +11,14 @@
  *
  *   node main.js --scene file.gltf|file.obj|file.ptxs [--camera preset | --camera-json file] [--width 256]
  *        [--height 256] [--frames 5] [--spp 5] [--bounces 5] [--out image.png|.ppm] [--dump-sum file.f32]
- *        [--device 0 | --gpus N | --devices 0,1,...] [--traversal 0..3] [--save-scene out.ptxs] [--light-material name]
+ *        [--device 0 | --gpus N | --devices 0,1,...] [--traversal 0..3] [--prune 1|2] [--save-scene out.ptxs] [--light-material name]
  *        [--checkpoint file.ptxc] [--checkpoint-every 16] [--compat-out image.png [--compat-rules 1|2] [--compat-gamma 0|1]]
  * --gpus N (devices 0 .. N-1) or --devices a,b,...: one PathTracer over several GPUs.  Frame f of every renderFrames call
  *   goes to device f mod N over the full image, the devices render side by side, and the per-device float buffers are
  *   summed by one RCCL all-reduce when the image (or a checkpoint) is read -- the reference's frame loop (main.js:391-438)
  *   for a whole node.  The same device listed N times rehearses that path on one GPU (summed by a kernel, no RCCL).
+ * --prune: rule for skipping BVH nodes behind the best hit (include/ptx.h): 2 = margin rule (default, fastest; equal to the
+ *   unpruned walk on every rendered frame tested, but not proven), 1 = rule with a proof (DESIGN.md section 4).
  * --checkpoint: progressive rendering like renderAsync (main.js:391-436): frames are rendered in batches of
  *   --checkpoint-every; after each batch {sum buffer, frames done} is written to the file (atomically, via rename).  If
  *   the file exists when the program starts, rendering resumes after the frames it holds (same size required); the
@@ -74,6 +76,7 @@ function main() {
   pt.uploadScene(scene);
   pt.setParams(a.width, a.height, camera, a.bounces, a.spp);
   if (a.traversal !== undefined) pt.setOption('traversal', a.traversal);
+  if (a.prune !== undefined) pt.setOption('prune', a.prune);
   if (a.compatOut) {
     if (a.checkpoint) throw new Error('--compat-out cannot be combined with --checkpoint (the 8-bit target is not checkpointed)');
     const rules = a.compatRules === undefined ? 1 : a.compatRules;
