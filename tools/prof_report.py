@@ -7,7 +7,7 @@ from separate passes, both in KB, FETCH_SIZE doubled on gfx950."""
 import glob, json, os, re, sqlite3, sys
 
 # the timed path-tracing kernel: any pipeline, COUNT = false (bench.py's count=1 pass for `roofline.actual` is left out)
-IS_RENDER = re.compile(r"k_render\w*<\w+, \w+, false>")
+IS_RENDER = re.compile(r"k_render\w*<[^>]*false>")
 
 tag, frames = sys.argv[1], int(sys.argv[2])
 base = os.path.join("gpurun_out", "prof_" + tag)
@@ -63,5 +63,14 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
                   "write_bytes_per_frame": per_frame["WRITE_SIZE"] * 1024.0, "hbm_bytes_per_frame": (2.0 * per_frame["FETCH_SIZE"] + per_frame["WRITE_SIZE"]) * 1024.0}
 if "SQ_INSTS_VALU" in per_frame and "SQ_THREAD_CYCLES_VALU" in per_frame:
     out["valu"] = {"wave_instr_per_frame": per_frame["SQ_INSTS_VALU"], "lane_utilisation": per_frame["SQ_THREAD_CYCLES_VALU"] / (64.0 * per_frame["SQ_INSTS_VALU"])}
+if "TA_TA_BUSY_sum" in per_frame and "GRBM_GUI_ACTIVE" in per_frame:
+    g = per_frame["GRBM_GUI_ACTIVE"] / 8.0
+    out["ta"] = {"note": "sums over the 256 TA/TCP instances (one per CU) divided by 256 x busy cycles; GRBM_GUI_ACTIVE is itself a sum over the 8 XCDs (it reads 8 x kernel time x clock), hence / 8",
+                 "gpu_busy_cycles_per_frame": g,
+                 "busy_frac": per_frame["TA_TA_BUSY_sum"] / (256.0 * g),
+                 "addr_stalled_by_tc_frac": per_frame.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum", 0.0) / (256.0 * g),
+                 "data_stalled_by_tc_frac": per_frame.get("TA_DATA_STALLED_BY_TC_CYCLES_sum", 0.0) / (256.0 * g),
+                 "tcp_tagconflict_stall_frac": per_frame.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", 0.0) / (256.0 * g),
+                 "tcp_pending_stall_frac": per_frame.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / (256.0 * g)}
 json.dump(out, open(os.path.join("profiles", f"{tag}_pmc.json"), "w"), indent=1)
 print("\n".join(lines))
