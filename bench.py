@@ -209,6 +209,20 @@ def main():
                     "lane_utilisation": prof["valu"]["lane_utilisation"], "frac": achieved_rate / peak_rate,
                     "counters_from": f"{prof_file} (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU of the same kernel and workload; committed profile, not measured in this run)",
                     "issue_cost_from": "profiles/r02_valu_issue_batch1.json (tools/dbg/valu_issue.hip)"}
+        # the vector-memory (texture-address) path: busy cycles per CU from the committed profile against the kernel's cycles.
+        # What a gather costs that unit is measured in profiles/r02_gather_rate.json (max(16, 0.6 x lines + 3 x L1 misses) cycles
+        # per load instruction); with the profile's loads, cache accesses and misses the model gives the busy time it measures.
+        vmem = None
+        if prof and "ta" in prof and default_kernel:
+            pf = prof["per_frame"]
+            busy_ms = pf["TA_TA_BUSY_sum"] / 256.0 / (CLOCK_GHZ * 1e9) * 1e3
+            loads = pf.get("SQ_INSTS_VMEM_RD")
+            vmem = {"unit": "texture-address path (TA/TCP), one per CU", "busy_ms_per_frame": busy_ms, "kernel_ms_per_frame": c["kernel_ms"] / frames_timed,
+                    "frac": busy_ms / (c["kernel_ms"] / frames_timed), "wave_loads_per_frame": loads,
+                    "busy_cycles_per_wave_load": pf["TA_TA_BUSY_sum"] / loads if loads else None,
+                    "model_cycles_per_wave_load": (0.6 * pf["TCP_TOTAL_CACHE_ACCESSES_sum"] + 3.0 * pf["TCP_TCC_READ_REQ_sum"]) / loads if loads and "TCP_TCC_READ_REQ_sum" in pf else None,
+                    "counters_from": f"{prof_file} (TA_TA_BUSY_sum, SQ_INSTS_VMEM_RD, TCP_TOTAL_CACHE_ACCESSES_sum, TCP_TCC_READ_REQ_sum; committed profile, not measured in this run)",
+                    "cost_model_from": "profiles/r02_gather_rate.json (tools/dbg/gather_rate.hip)"}
         # executed work: one frame with the kernel's own node / triangle counters switched on, outside the timed region
         ctx.set_option("count", 1)
         ctx.reset_counters()
@@ -227,7 +241,7 @@ def main():
                 "hbm_effective": {"bound": "hbm", "achieved": eff, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eff / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_total / launches,
                                   "note": "SURVEY 8d: 36Nv+40Nt+36Nh+76Nl+32Npf with the REFERENCE algorithm's counts (tests/golden/workload_counts.json) / kernel time; "
                                           "a speed-up measure over the unpruned reference traversal, not a utilisation: the kernel executes a fraction of that work and none of it comes from HBM"},
-                "actual": actual, "valu": valu}
+                "actual": actual, "valu": valu, "vmem": vmem}
         if valu:
             roof.update({"bound": "valu", "achieved": valu["wave_instr_per_frame"] * frames_timed / kernel_s / 1e9, "peak": SIMDS * CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INSTR,
                          "unit": "G wave-instr/s", "frac": valu["frac"]})
