@@ -134,6 +134,11 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned (headline:
  *                 1.45 x the time of rule 2, 2 % faster than traversal = 2).  Callers that need the guarantee use it or
  *                 traversal = 2.
+ *   "anyhit"    : 1 (default) = light-visibility rays (is_light_visible, glsl:353-363, and the shadow ray of glsl:439-442)
+ *                 stop at the first conclusive blocker instead of finding the closest hit: the shader uses only "is there a
+ *                 hit" and the closest hit's emission, and a hit on a triangle of emission (0,0,0) that no emissive triangle
+ *                 can precede -- decided by the rule of "prune" on boxes around the emissive triangles -- fixes both.  Same
+ *                 images and reference ray counters; pipeline 2 with pruning only.  0 = every ray is a closest-hit query
  *   "memo"      : 1 = reuse the per-pixel primary hit and the last light-attempt ray for the shadow ray
  *                 (default; both are bit-identical rays in the reference), 0 = trace every ray
  *   "count"     : 1 = also count node visits / triangle tests (slower), 0 = off (default)

@@ -21,6 +21,9 @@
 namespace ptx {
 
 #define PTX_MAX_CLS 8
+#ifndef PTX_MAX_LBOX
+#define PTX_MAX_LBOX 4      // boxes around the emissive triangles (light_bound): any-hit termination of light-visibility rays
+#endif
 #define PTX_CLS_DELTA 2.0e-3f   // a triangle belongs to a class when its unit normal is within this distance of +- the class normal
 #define PTX_CLS_WCAP 512.0f     // the class bound is derived for w_ray <= this (rays steeper than 1/512 to every class plane)
 
@@ -40,6 +43,10 @@ struct DScene {
     float two_rs, m_cap;   // twice its half-diagonal; largest M_ray the coefficients hold for }
     int n_cls;             // dominant plane normals of the scene's large flat triangles ("classes", unit vectors)
     V3 cls[PTX_MAX_CLS];
+    // any-hit termination of light-visibility rays (pipeline 2; 0 boxes = off): boxes around ALL triangles with a non-zero
+    // emission (padded for the margin rule), and the largest pruning coefficients among those triangles
+    uint32_t n_lbox, lcoefs;
+    float lbox[PTX_MAX_LBOX][6];   // min.xyz, max.xyz
 };
 
 struct DParams {
@@ -161,6 +168,32 @@ __device__ __forceinline__ uint32_t pack_kappa(Kappa k) {
     return (ha << 16) | (hb & 0xFFFFu);
 }
 __device__ __forceinline__ Kappa unpack_kappa(uint32_t w) { Kappa k; k.k = __uint_as_float(w & 0xFFFF0000u); k.k2 = __uint_as_float(w << 16); return k; }
+
+// Light-visibility rays (glsl:353-363, 439-442) consume only "is there a hit" and the emission of the closest one.  A hit on
+// a triangle WITHOUT emission settles both -- hit, not visible -- as soon as no emissive triangle can be hit nearer; the
+// closest hit itself is then another triangle without emission or that one, and every such triangle has emission (0,0,0),
+// so the shader's result is the same whichever of them is reported.  light_bound returns a distance tl such that
+//     prune_far<PRUNE>(tl, prune_limit<PRUNE>(t_b), S.lcoefs, kappa)
+// means "no emissive triangle yields a computed t <= t_b" -- the pruning rule applied to the boxes around the emissive
+// triangles instead of BVH nodes (the rule only needs a box that contains the triangle).  A box may be left out when the
+// ray cannot hit anything in it: PRUNE = 2, boxes padded on upload: the slab test misses it; PRUNE = 1 (provable): it lies
+// wholly behind the ray even after growing it by the position-error bound (t <= tFar + slack and t > 0 for any hit).
+template <int PRUNE>
+__device__ __forceinline__ float light_bound(const DScene& S, V3 o, V3 inv, Kappa kap) {
+    float tl = 3.0e38f;
+    const float slack = PRUNE == 1 ? coef_other(S.lcoefs) * kap.k + coef_class(S.lcoefs) * kap.k2 : 0.0f;
+    for (uint32_t k = 0; k < S.n_lbox; k++) {
+        const float* b = S.lbox[k];
+        const float ax = (b[0] - o.x) * inv.x, bx = (b[3] - o.x) * inv.x;
+        const float ay = (b[1] - o.y) * inv.y, by = (b[4] - o.y) * inv.y;
+        const float az = (b[2] - o.z) * inv.z, bz = (b[5] - o.z) * inv.z;
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+        const bool out = PRUNE == 2 ? (tn > tf || tf <= 0.0f) : (tf * (1.0f - PTX_PRUNE_SAFE_REL) + slack < 0.0f);   // false for NaN
+        if (!out) tl = fminf(tl, tn);
+    }
+    return tl;
+}
 
 // 32-bit byte offsets from a uniform base: lets the compiler use the SGPR-base + VGPR-offset addressing form.
 __device__ __forceinline__ float4 ld16(const float4* base, uint32_t byte_off) {
@@ -293,7 +326,7 @@ __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, f
             const float4 r0 = ld16(S.pairs, pbyte), r1 = ld16(S.pairs, pbyte + 16u), r2 = ld16(S.pairs, pbyte + 32u),
                          r3 = ld16(S.pairs, pbyte + 48u), r4 = ld16(S.pairs, pbyte + 64u);
             if (PRUNE == 1 && first_pair && prune_far<1>(tn, limit, __float_as_uint(r4.w), kappa)) break;   // the leaf's own coefficients
-            const int rem = __float_as_int(r4.z);
+            const int rem = __float_as_int(r4.z) & 0xFF;      // bits 16, 17: emission flags of A and B (pipeline 2's any-hit rule)
             bool hA, hB;
             float tA, tB;
             tri_test2(o, d, r0, r1, r2, r3, r4, hA, hB, tA, tB);

@@ -12,6 +12,10 @@
 // (prune_far, ptx_kernels.h: provably for PRUNE = 1, by the heuristic margin for PRUNE = 2; front-to-back order makes this
 // frequent).  Inner nodes are cut in the WALK phase by the same rule with the coefficient stored in the node.
 // A ray is finished when its walk has ended and the queue head has passed its newest item (items are consumed in order).
+// Light-visibility rays end early (S.n_lbox > 0): a TRI lane that finds a hit on a triangle without emission, nearer than any
+// emissive triangle can be (light_bound, ptx_kernels.h), stores it with distance 0; that drops the ray's queued leaves at
+// dequeue and ends its walk at the next WALK phase.  The key carries the emission flag of its triangle in bit 0
+// (t bits << 32 | slot << 1 | flag: still ordered by (t, slot)).
 #pragma once
 #include "ptx_wave.h"
 #include <type_traits>
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
     __shared__ uint2 queue[PTX_POOL_QCAP];
     __shared__ uint32_t kap[64];                     // PRUNE = 1: packed kappa pair of the lane's ray (ray_kappa), read by whoever tests its leaves
+    __shared__ float tlm[64];                        // PRUNE != 0: light_bound of the lane's ray if it is a light-visibility ray, else -3e38
     const uint32_t lane = threadIdx.x;
     const LdsLane L{lds + lane};
     const uint32_t npix = P.W * P.H;
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     int flags = F_ALIVE;
     V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f), inv = mk(0.f, 0.f, 0.f);
     float limit = 3.0e38f;
+    if (PRUNE) tlm[lane] = -3.0e38f;
     uint32_t i = 0xFFFFFFFFu, nbase = 0;
     const uint32_t N = (uint32_t)S.N;
     const float4* nodes_hi = S.nodes + 1;            // second half of a node record through its own base: no offset add
@@ -106,13 +112,20 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
         // TRI phases are load-latency bound (five 16-B loads, then one burst of packed math): their instructions go first
         if (phase == 1) __builtin_amdgcn_s_setprio(PTX_POOL_TRI_PRIO); else __builtin_amdgcn_s_setprio(0);
         if (phase == 0) {
-            if (PRUNE) limit = prune_limit<PRUNE>(__uint_as_float((uint32_t)(keys[lane] >> 32)));
             Kappa kappa = {0.f, 0.f};
             if (PRUNE == 1) kappa = unpack_kappa(kap[lane]);
+            bool w0 = walking;
+            if (PRUNE) {
+                const unsigned long long key = keys[lane];
+                const float tb = __uint_as_float((uint32_t)(key >> 32));
+                limit = prune_limit<PRUNE>(tb);
+                // any-hit rule for light-visibility rays: a TRI phase found a conclusive blocker (distance bits 0, below)
+                if (tb == 0.0f) { i = 0xFFFFFFFFu; w0 = false; }
+            }
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
-            const bool ordered = S.oct_stride != 0u && __ballot(walking && (flags & F_INF)) == 0ull;
+            const bool ordered = S.oct_stride != 0u && __ballot(w0 && (flags & F_INF)) == 0ull;
             auto walk = [&](auto MODE) {
-                bool w = walking;                                 // trav && i < N, carried from one step to the next
+                bool w = w0;                                      // trav && i < N, carried from one step to the next
 #pragma nounroll
                 for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
                     if (tail - head > (uint32_t)(PTX_POOL_QCAP - 64)) break;
@@ -187,13 +200,14 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             while (__ballot(more) != 0ull) {
                 if (COUNT) { d_tri += more ? 1u : 0u; if (lane == 0) d_tri_s += 64u; }
                 if (more) {
-                    const int rem = __float_as_int(r4.z);      // triangles of the leaf from this pair on (>= 1)
+                    const int rz = __float_as_int(r4.z);
+                    const int rem = rz & 0xFF;                 // triangles of the leaf from this pair on (>= 1); bits 16 / 17: A / B emit
                     bool hA, hB;
                     float tA, tB;
                     tri_test2(o, d, r0, r1, r2, r3, r4, hA, hB, tA, tB);
                     if (COUNT) cnt_tris += rem >= 2 ? 2u : 1u;
-                    if (hA && tA < bt) { bt = tA; bk = k; }
-                    if (hB && tB < bt) { bt = tB; bk = k + 1u; }
+                    if (hA && tA < bt) { bt = tA; bk = (k << 1) | ((uint32_t)(rz >> 16) & 1u); }
+                    if (hB && tB < bt) { bt = tB; bk = ((k + 1u) << 1) | ((uint32_t)(rz >> 17) & 1u); }
                     more = rem > 2;
                     k += 2u;
                     if (more) {
@@ -203,7 +217,17 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     }
                 }
             }
-            if (bt < 1.0e38f) atomicMin(&keys[owner], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)bk);
+            if (bt < 1.0e38f) {
+                // any-hit rule for light-visibility rays: a hit on a triangle without emission, nearer than anything emissive can
+                // be (light_bound of the owner's ray; -3e38 for other rays), settles the ray: stored with distance 0 it is "a
+                // hit", ends the owner's walk at its next WALK phase and puts every leaf still queued out of reach
+                if (PRUNE && S.n_lbox != 0u && (bk & 1u) == 0u) {
+                    Kappa ok = {0.f, 0.f};
+                    if (PRUNE == 1) ok = unpack_kappa(kap[owner]);
+                    if (prune_far<PRUNE>(tlm[owner], prune_limit<PRUNE>(bt), S.lcoefs, ok)) bt = 0.0f;
+                }
+                atomicMin(&keys[owner], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)bk);
+            }
         } else {
             if (COUNT) { d_shade += need_shade ? 1u : 0u; if (lane == 0) d_shade_s += 64u; }
             bool run_shade = need_shade && (flags & F_TASK);      // a finished ray (or a pending cached primary hit)
@@ -266,7 +290,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     const unsigned long long key = keys[lane];
                     t = __uint_as_float((uint32_t)(key >> 32));
                     hit = t < 1.0e38f;
-                    if (hit) tri = __float_as_int(ld16(S.tris, (uint32_t)key * 48u).w);
+                    if (hit) tri = __float_as_int(ld16(S.tris, ((uint32_t)key >> 1) * 48u).w);
                 }
                 bool act = run_shade;
                 int st = SH_TRACE;
@@ -305,7 +329,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                 keys[lane] = PTX_POOL_KEY_NONE;
-                if (PRUNE == 1) kap[lane] = pack_kappa(ray_kappa(S, ro, rd));
+                uint32_t pk = 0u;
+                if (PRUNE == 1) { pk = pack_kappa(ray_kappa(S, ro, rd)); kap[lane] = pk; }
                 limit = 3.0e38f;
                 i = 0;
                 lastpos = head;
@@ -314,6 +339,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 const bool deg = inv_degenerate(inv);
                 flags = deg ? (flags | F_INF) : (flags & ~F_INF);
                 nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
+                if (PRUNE && S.n_lbox != 0u)                     // glsl:353-363 / 439-442: only "hit" and the closest hit's emission are used
+                    tlm[lane] = (p.stage() != ST_PATH && !deg) ? light_bound<PRUNE>(S, ro, inv, unpack_kappa(pk)) : -3.0e38f;
             }
             w_traced += (uint32_t)__popcll(__ballot(start_trav));
         }

@@ -22,7 +22,7 @@ def setup(ctx, ptx, name, w, h, spp=4, bounces=4, **opts):
     p = ptx.config_params(name, w, h, spp, bounces)
     ctx.upload_scene(s)
     ctx.set_params(p)
-    for k, v in {**dict(traversal=3, prune=2, memo=1, count=0, frame_batch=0, pipeline=2, tasks_per_wave=128), **opts}.items():
+    for k, v in {**dict(traversal=3, prune=2, memo=1, count=0, frame_batch=0, pipeline=2, tasks_per_wave=128, anyhit=1), **opts}.items():
         ctx.set_option(k, v)
     ctx.reset_accum()
     ctx.reset_counters()
@@ -214,6 +214,57 @@ def test_edge_cases(gpu_ctx, ptx, orc):
             gpu_ctx.set_option("pipeline", pipeline); gpu_ctx.set_option("traversal", traversal)
             gpu_ctx.reset_accum(); gpu_ctx.render_frames([1000, 1001])
             assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (pipeline, traversal)
+
+
+def _with_emitters(ptx, name, emit):
+    """The scene with the emission of some triangles replaced: emit = {triangle: (r, g, b)}; the light list is rebuilt as
+    utils/triangleMapper.js:71 does (any channel > 0)."""
+    import copy
+    s = copy.deepcopy(ptx.load_scene(name))
+    em = s.emissions.reshape(-1, 3).copy()
+    for tri, e in emit.items():
+        em[tri] = e
+    s.emissions = np.ascontiguousarray(em.reshape(-1), dtype=np.float32)
+    s.light_tri = np.ascontiguousarray(np.nonzero((em > 0).any(axis=1))[0], dtype=np.int32)
+    s.L = int(s.light_tri.size)
+    s.validate()
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prune", [1, 2])
+def test_anyhit_light_visibility(gpu_ctx, ptx, orc, prune):
+    """Light-visibility rays stop at the first conclusive blocker (option anyhit, default on): same sums and reference
+    counters as with the option off and as the oracle -- on the BASELINE scenes, with emitters in several far-apart
+    clusters, with more emitters than boxes, and with a non-light triangle of non-zero (negative) emission, which blocks
+    like a light of another emission (glsl:353-363) and must never count as a conclusive blocker."""
+    far = {0: (50, 50, 50), 1: (50, 50, 50), 40: (20, 30, 40), 41: (20, 30, 40), 100: (5, 0, 0), 77: (0, 9, 0)}
+    many = {t: (50, 50, 50) for t in range(0, 122, 5)}
+    cases = [("my_cornell_6", None, (48, 48), 4, 5), ("pixar_room", None, (64, 36), 3, 6), ("bedroom2_v5", None, (48, 27), 3, 4),
+             ("my_cornell_6", far, (40, 40), 3, 5), ("my_cornell_6", many, (40, 40), 3, 4),
+             ("my_cornell_6", {60: (-5, 0, 0), 61: (0, 0, -1)}, (40, 40), 4, 5)]
+    for name, emit, size, spp, bounces in cases:
+        s = ptx.load_scene(name) if emit is None else _with_emitters(ptx, name, emit)
+        p = ptx.config_params(name, *size, spp, bounces)
+        gpu_ctx.upload_scene(s); gpu_ctx.set_params(p)
+        ts = ptx.scene.timestamps(2)
+        want, oc = orc.render_frames(s, p, ts)
+        assert want.max() > 0
+        visits = {}
+        for anyhit in (0, 1):
+            for k, v in dict(traversal=3, prune=prune, memo=1, count=1, pipeline=2, anyhit=anyhit, frame_batch=0).items():
+                gpu_ctx.set_option(k, v)
+            gpu_ctx.reset_accum(); gpu_ctx.reset_counters()
+            gpu_ctx.render_frames(ts)
+            assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (name, emit is not None, anyhit)
+            c = gpu_ctx.counters()
+            for key in ("samples", "rays", "ray_hits", "light_attempts"):
+                assert c[key] == oc[key], (name, key, anyhit)
+            visits[anyhit] = c["node_visits"]
+        assert visits[1] <= visits[0]
+        if prune == 2 and emit is None:
+            assert visits[1] < 0.95 * visits[0], (name, visits)        # it does end rays early
+    gpu_ctx.set_option("count", 0); gpu_ctx.set_option("prune", 2)
 
 
 def test_task_list_shapes(gpu_ctx, ptx, orc):
