@@ -31,7 +31,8 @@
 #endif
 
 #ifndef PTX_POOL_WALK_KEEP
-#define PTX_POOL_WALK_KEEP 0     // leave a WALK phase early once no more than KEEP/8 of the lanes it started with still walk
+#define PTX_POOL_WALK_KEEP 5     // leave a WALK phase early once no more than KEEP/8 of the lanes it started with still walk (with any-hit
+                                 // termination: 0 / 4 / 5 / 6 -> 75.5 / 73.9 / 73.2 / 73.2 ms per headline frame)
 #endif
 
 #ifndef PTX_POOL_TRI_PRIO
