@@ -131,8 +131,8 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 1 = provable rule: a node is skipped only when a rounding-error bound of the shader's own triangle test
  *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
  *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles
- *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned (headline:
- *                 1.45 x the time of rule 2, 2 % faster than traversal = 2).  Callers that need the guarantee use it or
+ *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned there (pixar_room:
+ *                 1.8 x the time of rule 2; the other BASELINE scenes: 1.12 - 1.15 x).  Callers that need the guarantee use it or
  *                 traversal = 2.
  *   "anyhit"    : 1 (default) = light-visibility rays (is_light_visible, glsl:353-363, and the shadow ray of glsl:439-442)
  *                 stop at the first conclusive blocker instead of finding the closest hit: the shader uses only "is there a
