@@ -391,10 +391,14 @@ static hipError_t scratch_for_device(int device, unsigned char** out) {   // `de
 
 // traversal option: bit 0 = best-t pruning, bit 1 = walk the leaf-SAH tree instead of the reference tree
 static inline int prune_mode(const ptx_ctx* c) { return (c->opt_traversal & 1) ? c->opt_prune : 0; }   // the kernels' PRUNE parameter
+static inline float __uint_as_float_host(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline DScene scene_view(const ptx_ctx* c) {
     DScene S = c->S;
     if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; S.oct_stride = (uint32_t)c->N_sah * 32u; S.ref_base = 8u * S.oct_stride; }
     if (!c->opt_anyhit) S.n_lbox = 0;              // (kernels without pruning never look at the boxes)
+    // provable rule: with emitters whose position-error coefficient is this large the bound never lets a ray stop (pixar_room's
+    // lamp: c_o = 0.054, slack = c_o * kappa of several scene units), and computing it would only cost time
+    if (prune_mode(c) == 1 && !(__uint_as_float_host(S.lcoefs & 0x7FFF0000u) <= 0.01f)) S.n_lbox = 0;
     return S;
 }
 
@@ -1043,6 +1047,12 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
             const TriCoef c = {rmo.query((size_t)i + 1, end), rmc.query((size_t)i + 1, end)};
             nodes[2 * (size_t)i + 1].w = bits((int32_t)(0x80000000u | pack_coefs(c)));
         }
+    }
+    // blocker cache of pipeline 2: every slot knows the reference-tree node of its leaf (the last one, should leaves share slots:
+    // such scenes are not rendered by pipeline 2)
+    for (uint32_t i = 0; i < N; i++) {
+        if (sc->node_first[i] == -2) continue;
+        for (int32_t q = 0; q < sc->node_count[i]; q++) tris[3 * ((size_t)sc->node_first[i] + q) + 2].w = bits((int32_t)i);
     }
     // ---- any-hit termination of light-visibility rays (ptx_kernels.h light_bound): which slots emit, boxes around them
     std::vector<uint8_t> slot_emits(T, 0);

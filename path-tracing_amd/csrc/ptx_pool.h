@@ -16,6 +16,12 @@
 // emissive triangle can be (light_bound, ptx_kernels.h), stores it with distance 0; that drops the ray's queued leaves at
 // dequeue and ends its walk at the next WALK phase.  The key carries the emission flag of its triangle in bit 0
 // (t bits << 32 | slot << 1 | flag: still ordered by (t, slot)).
+// Blocker cache: 92 % of the light attempts are blocked and the next attempt of the same bounce (same origin, a direction a few
+// degrees off) is blocked by the same triangle in every second case.  A lane remembers the leaf of its last blocker (the node
+// record's byte offset, looked up by slot in the triangle record); when its next attempt starts, the leaf's box is tested at
+// once and, if hit, the leaf goes into the queue before the walk has taken a step (the reference tests that leaf too: its
+// box passes, hence every ancestor's).  A conclusive hit in the next TRI phase ends the ray after at most one WALK phase
+// (forcing a TRI phase right after such a SHADE phase was measured: no gain).
 #pragma once
 #include "ptx_wave.h"
 #include <type_traits>
@@ -41,6 +47,10 @@
 
 #ifndef PTX_POOL_DEFER_CACHED
 #define PTX_POOL_DEFER_CACHED 1  // 1: one pass through shade_step per SHADE phase (cached primary hits wait for the next phase)
+#endif
+#ifndef PTX_POOL_CACHE_RESET
+#define PTX_POOL_CACHE_RESET 0   // 0: the blocker cache survives bounces and samples (63.6 -> 62.7 ms per headline frame: the next bounce is
+                                 // often shadowed by the same object); a separate entry for bounce 0 (same point for every sample): no gain
 #endif
 #ifndef PTX_POOL_MIN_WAVES
 #define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
@@ -88,11 +98,13 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     uint32_t head = 0, tail = 0;                     // wave-uniform queue cursors (free running)
     // work counters as wave totals in scalar registers: every increment is a ballot + popcount in wave-uniform control flow
     uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
+    uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
 
     for (;;) {
         const bool trav = (flags & F_TRAV) != 0;
+        if (PRUNE && trav && (uint32_t)(keys[lane] >> 32) == 0u) i = 0xFFFFFFFFu;   // settled by a conclusive blocker (distance bits 0): nothing left to walk
         const bool walking = trav && i < N;
         const bool need_shade = (flags & F_ALIVE) && !(trav && (i < N || (int32_t)(head - lastpos) < 0));
         const int nW = __popcll(__ballot(walking)), nS = __popcll(__ballot(need_shade));
@@ -291,7 +303,17 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     const unsigned long long key = keys[lane];
                     t = __uint_as_float((uint32_t)(key >> 32));
                     hit = t < 1.0e38f;
-                    if (hit) tri = __float_as_int(ld16(S.tris, ((uint32_t)key >> 1) * 48u).w);
+                    if (hit) {
+                        const uint32_t slot = (uint32_t)key >> 1;
+                        if (p.stage() != ST_PATH && ((uint32_t)key & 1u) == 0u) {
+                            // a light-visibility ray stopped by a triangle without emission: shade_step needs no index (tri < 0);
+                            // the blocker's leaf is remembered for the next attempt instead
+                            tri = -1;
+                            c_noff = S.ref_base + ((uint32_t)__float_as_int(ld16(S.tris, slot * 48u + 32u).w) << 5);
+                        } else {
+                            tri = __float_as_int(ld16(S.tris, slot * 48u).w);
+                        }
+                    }
                 }
                 bool act = run_shade;
                 int st = SH_TRACE;
@@ -327,6 +349,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 w_pf += (uint32_t)__popcll(__ballot(done));
             }
             // (3) start the traversal of the lanes that now hold a fresh ray
+            bool probe = false;
+            uint32_t probe_item = 0;
+            float probe_tn = 0.f;
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                 keys[lane] = PTX_POOL_KEY_NONE;
@@ -340,8 +365,27 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 const bool deg = inv_degenerate(inv);
                 flags = deg ? (flags | F_INF) : (flags & ~F_INF);
                 nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
-                if (PRUNE && S.n_lbox != 0u)                     // glsl:353-363 / 439-442: only "hit" and the closest hit's emission are used
-                    tlm[lane] = (p.stage() != ST_PATH && !deg) ? light_bound<PRUNE>(S, ro, inv, unpack_kappa(pk)) : -3.0e38f;
+                const bool lightray = p.stage() != ST_PATH;
+#if PTX_POOL_CACHE_RESET
+                if (!lightray) c_noff = 0xFFFFFFFFu;         // 1: the cache belongs to the attempts of one bounce
+#endif
+                if (PRUNE && S.n_lbox != 0u) {               // glsl:353-363 / 439-442: only "hit" and the closest hit's emission are used
+                    tlm[lane] = (lightray && !deg) ? light_bound<PRUNE>(S, ro, inv, unpack_kappa(pk)) : -3.0e38f;
+                    if (lightray && !deg && c_noff != 0xFFFFFFFFu) {          // blocker cache: the last blocker's leaf, if its box is hit
+                        const float4 a = ld16(S.nodes, c_noff), b = ld16(nodes_hi, c_noff);
+                        probe = slab_node(ro, inv, a, b, probe_tn) && __float_as_int(b.w) >= 0;
+                        probe_item = (uint32_t)__float_as_int(b.w) & 0x00FFFFFFu;
+                    }
+                }
+            }
+            if (PRUNE) {                                         // wave-uniform: queue the cached leaves (at most 64; len < 64 in a SHADE phase)
+                const unsigned long long m = __ballot(probe);
+                if (probe) {
+                    const uint32_t pos = tail + below(m);
+                    queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(probe_item | (lane << 24), __float_as_uint(probe_tn));
+                    lastpos = pos + 1u;
+                }
+                tail += (uint32_t)__popcll(m);
             }
             w_traced += (uint32_t)__popcll(__ballot(start_trav));
         }

@@ -113,7 +113,7 @@ __device__ __forceinline__ int shade_step(const DScene& S, const DParams& P, PT&
         c.rays++;
         const V3 lem = mk(S.light[p.li() * 6 + 4]);
         V3 bem = mk(0.f, 0.f, 0.f);
-        if (hit) { c.ray_hits++; bem = mk(S.attrE[tri]); }
+        if (hit) { c.ray_hits++; if (tri >= 0) bem = mk(S.attrE[tri]); }   // tri < 0: a triangle known to have emission (0,0,0) (pipeline 2)
         const bool visible = !(hit && any_ne(bem, lem));                  // glsl:353-363
         if (visible || p.attempts() >= 10) {
             p.set_lpdf(visible ? S.light[p.li() * 6 + 5].x : 1.0f);            // glsl:389-395
@@ -129,7 +129,7 @@ __device__ __forceinline__ int shade_step(const DScene& S, const DParams& P, PT&
         // else: another attempt (generated below)
     } else { // ST_SHADOW (only without MEMO)
         c.rays++;
-        if (hit) { c.ray_hits++; sh_em = mk(S.attrE[tri]); }
+        if (hit) { c.ray_hits++; if (tri >= 0) sh_em = mk(S.attrE[tri]); }
         sh_hits = hit;
         do_direct = true;
         do_bounce = true;
