@@ -135,6 +135,26 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 // any-hit rule for light-visibility rays: a TRI phase found a conclusive blocker (distance bits 0, below)
                 if (tb == 0.0f) { i = 0xFFFFFFFFu; w0 = false; }
             }
+            // blocker cache: before its first step a light ray tests the box of the leaf that blocked the previous attempt and,
+            // if hit, queues that leaf (the reference tests it too: its box passes, hence every ancestor's)
+            if (PRUNE && __ballot(w0 && (flags & F_PROBE)) != 0ull) {
+                bool probe = false;
+                uint32_t probe_item = 0;
+                float probe_tn = 0.f;
+                if (w0 && (flags & F_PROBE)) {
+                    const float4 a = ld16(S.nodes, c_noff), b = ld16(nodes_hi, c_noff);
+                    probe = slab_node(ro, inv, a, b, probe_tn) && __float_as_int(b.w) >= 0;
+                    probe_item = (uint32_t)__float_as_int(b.w) & 0x00FFFFFFu;
+                    flags &= ~F_PROBE;
+                }
+                const unsigned long long m = __ballot(probe);     // at most 64 and len < 64 here
+                if (probe) {
+                    const uint32_t pos = tail + below(m);
+                    queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(probe_item | (lane << 24), __float_as_uint(probe_tn));
+                    lastpos = pos + 1u;
+                }
+                tail += (uint32_t)__popcll(m);
+            }
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
             const bool ordered = S.oct_stride != 0u && __ballot(w0 && (flags & F_INF)) == 0ull;
             auto walk = [&](auto MODE) {
@@ -349,9 +369,6 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 w_pf += (uint32_t)__popcll(__ballot(done));
             }
             // (3) start the traversal of the lanes that now hold a fresh ray
-            bool probe = false;
-            uint32_t probe_item = 0;
-            float probe_tn = 0.f;
             if (start_trav) {
                 inv = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
                 keys[lane] = PTX_POOL_KEY_NONE;
@@ -360,10 +377,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 limit = 3.0e38f;
                 i = 0;
                 lastpos = head;
-                flags |= F_TRAV;
                 // rays with an infinite or NaN 1/d component walk the reference tree with the selecting slab test (slab_node_ref)
                 const bool deg = inv_degenerate(inv);
-                flags = deg ? (flags | F_INF) : (flags & ~F_INF);
+                flags = (flags & ~(F_INF | F_PROBE)) | F_TRAV | (deg ? F_INF : 0);
                 nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
                 const bool lightray = p.stage() != ST_PATH;
 #if PTX_POOL_CACHE_RESET
@@ -371,21 +387,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
 #endif
                 if (PRUNE && S.n_lbox != 0u) {               // glsl:353-363 / 439-442: only "hit" and the closest hit's emission are used
                     tlm[lane] = (lightray && !deg) ? light_bound<PRUNE>(S, ro, inv, unpack_kappa(pk)) : -3.0e38f;
-                    if (lightray && !deg && c_noff != 0xFFFFFFFFu) {          // blocker cache: the last blocker's leaf, if its box is hit
-                        const float4 a = ld16(S.nodes, c_noff), b = ld16(nodes_hi, c_noff);
-                        probe = slab_node(ro, inv, a, b, probe_tn) && __float_as_int(b.w) >= 0;
-                        probe_item = (uint32_t)__float_as_int(b.w) & 0x00FFFFFFu;
-                    }
+                    if (lightray && !deg && c_noff != 0xFFFFFFFFu) flags |= F_PROBE;   // blocker cache: tested when the walk starts
                 }
-            }
-            if (PRUNE) {                                         // wave-uniform: queue the cached leaves (at most 64; len < 64 in a SHADE phase)
-                const unsigned long long m = __ballot(probe);
-                if (probe) {
-                    const uint32_t pos = tail + below(m);
-                    queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(probe_item | (lane << 24), __float_as_uint(probe_tn));
-                    lastpos = pos + 1u;
-                }
-                tail += (uint32_t)__popcll(m);
             }
             w_traced += (uint32_t)__popcll(__ballot(start_trav));
         }

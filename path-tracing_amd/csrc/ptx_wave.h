@@ -105,7 +105,8 @@ struct PathLds {
     __device__ __forceinline__ void set_bounce(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & 0xFFFF) | (v << 16)); }
 };
 
-enum { F_ALIVE = 1, F_TASK = 2, F_TRAV = 4, F_CACHED = 8, F_INF = 16 /* 1/d has an infinite or NaN component */ };
+enum { F_ALIVE = 1, F_TASK = 2, F_TRAV = 4, F_CACHED = 8, F_INF = 16 /* 1/d has an infinite or NaN component */,
+       F_PROBE = 32 /* pipeline 2: a light ray that has not yet tested the box of its blocker-cache leaf */ };
 
 template <int PRUNE, bool MEMO, bool COUNT>
 __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S, DParams P, const int32_t* __restrict__ timestamps,
