@@ -132,7 +132,7 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
  *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles
  *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned there (pixar_room:
- *                 1.8 x the time of rule 2; the other BASELINE scenes: 1.12 - 1.15 x).  Callers that need the guarantee use it or
+ *                 2.1 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
  *                 traversal = 2.
  *   "anyhit"    : 1 (default) = light-visibility rays (is_light_visible, glsl:353-363, and the shadow ray of glsl:439-442)
  *                 stop at the first conclusive blocker instead of finding the closest hit: the shader uses only "is there a
@@ -222,6 +222,10 @@ typedef struct ptx_selfcheck_result {
     uint64_t rays, hits, mismatches;
     float first[16][8];
     int32_t first_tri[16][2]; /* -2 = unused entry */
+    /* option "anyhit": rays whose unpruned closest hit is an emissive triangle, and how many of those the light bound
+     * (the rule of option "prune" on the boxes around the emitters) would have let end on a blocker farther away.
+     * Families 8 .. 11 are families 1, 3, 4, 7 aimed at the emissive triangles. */
+    uint64_t emitter_hits, anyhit_violations;
 } ptx_selfcheck_result;
 int ptx_selfcheck_pruning(ptx_ctx *ctx, uint32_t family, uint64_t n_rays, uint32_t seed, ptx_selfcheck_result *out);
 /* Primary-ray closest hits for every pixel (glsl:501-514 + 207-249); W*H entries, row 0 = bottom. */

@@ -56,7 +56,8 @@ class CCounters(C.Structure):
 
 
 class CSelfcheck(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("hits", C.c_uint64), ("mismatches", C.c_uint64), ("first", (C.c_float * 8) * 16), ("first_tri", (C.c_int32 * 2) * 16)]
+    _fields_ = [("rays", C.c_uint64), ("hits", C.c_uint64), ("mismatches", C.c_uint64), ("first", (C.c_float * 8) * 16), ("first_tri", (C.c_int32 * 2) * 16),
+                ("emitter_hits", C.c_uint64), ("anyhit_violations", C.c_uint64)]
 
 
 def lib_path():
@@ -267,7 +268,8 @@ class Context:
             if r.first_tri[q][0] != -2 or r.first_tri[q][1] != -2:
                 v = [float(x) for x in r.first[q]]
                 first.append((v[0:3], v[3:6], v[6], v[7], int(r.first_tri[q][0]), int(r.first_tri[q][1])))
-        return {"rays": int(r.rays), "hits": int(r.hits), "mismatches": int(r.mismatches), "first": first}
+        return {"rays": int(r.rays), "hits": int(r.hits), "mismatches": int(r.mismatches), "first": first,
+                "emitter_hits": int(r.emitter_hits), "anyhit_violations": int(r.anyhit_violations)}
 
     def primary_hits(self):
         tri = np.zeros((self.params.height, self.params.width), dtype=np.int32)

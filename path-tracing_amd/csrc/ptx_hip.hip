@@ -190,8 +190,12 @@ __global__ __launch_bounds__(64) void k_store_timestamps(TsBlock ts, int32_t* __
 //   1 surface point -> point on another triangle    5 grazing directions of the hemisphere about the surface's own normal
 //   2 in the plane of the own triangle +- tiny tilt 6 (nearly) axis-parallel rays: huge / infinite 1/d components
 //   3 grazing a LARGE triangle from far away        7 surface point -> vertex / edge of another triangle
-struct CheckArgs { unsigned long long n; uint32_t seed, family, n_big; const uint32_t* big; V3 bmin, bmax; };
-struct CheckOut { unsigned long long rays, hits, mismatches; float first[16][8]; int first_tri[16][2]; };
+//   8 .. 11 = families 1, 3, 4, 7 aimed at the EMISSIVE triangles only: what the any-hit rule for light-visibility rays rests
+//   on.  For every ray (of any family) whose unpruned closest hit is an emissive triangle at t0 the kernel also checks that
+//   light_bound does not claim "no emissive triangle can be hit at or before t0" -- the only way that rule could end a ray
+//   on a blocker although an emitter is nearer (a blocker's t_b >= t0, and the claim is monotone in t).
+struct CheckArgs { unsigned long long n; uint32_t seed, family, n_big, n_emit; const uint32_t* big; const uint32_t* emit; V3 bmin, bmax; };
+struct CheckOut { unsigned long long rays, hits, mismatches; float first[16][8]; int first_tri[16][2]; unsigned long long emitter_hits, anyhit_violations; };
 
 __device__ __forceinline__ uint32_t hash32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 struct CheckRng {
@@ -210,7 +214,9 @@ __global__ __launch_bounds__(64) void k_selfcheck(DScene S, CheckArgs A, CheckOu
     const uint32_t T = (uint32_t)S.T;
     auto tri = [&](uint32_t k, V3& v0, V3& e1, V3& e2) { v0 = mk(ld16(S.tris, k * 48u)); e1 = mk(ld16(S.tris, k * 48u + 16u)); e2 = mk(ld16(S.tris, k * 48u + 32u)); };
     auto point_on = [&](V3 v0, V3 e1, V3 e2) { float a = R.f(), b = R.f(); if (a + b > 1.0f) { a = 1.0f - a; b = 1.0f - b; } return (v0 + e1 * a) + e2 * b; };
-    auto pick = [&](bool prefer_big) { return (prefer_big && A.n_big && (R.u() & 1u)) ? A.big[R.u() % A.n_big] : R.u() % T; };
+    const bool at_emitters = A.family >= 8u && A.n_emit != 0u;
+    const uint32_t family = A.family >= 8u ? (A.family == 8u ? 1u : (A.family == 9u ? 3u : (A.family == 10u ? 4u : 7u))) : A.family;
+    auto pick = [&](bool prefer_big) { return at_emitters ? A.emit[R.u() % A.n_emit] : ((prefer_big && A.n_big && (R.u() & 1u)) ? A.big[R.u() % A.n_big] : R.u() % T); };
     const V3 ext = A.bmax - A.bmin;
     const float scale = fmaxf(fmaxf(ext.x, ext.y), ext.z);
     V3 a0, a1, a2;
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(64) void k_selfcheck(DScene S, CheckArgs A, CheckOu
     V3 o = point_on(a0, a1, a2), d = mk(1.f, 0.f, 0.f);
     const V3 nA = normalize(cross(a1, a2));
     auto in_plane = [&](V3 e1, V3 e2) { return normalize(e1 * (R.f() - 0.5f) + e2 * (R.f() - 0.5f)); };
-    switch (A.family) {
+    switch (family) {
         case 0: {
             const float z = 2.0f * R.f() - 1.0f, ph = 6.2831853f * R.f(), r = sqrtf(fmaxf(0.f, 1.0f - z * z));
             d = mk(r * cosf(ph), r * sinf(ph), z);
@@ -275,11 +281,25 @@ __global__ __launch_bounds__(64) void k_selfcheck(DScene S, CheckArgs A, CheckOu
     if (PAIRS) { h0 = closest_hit_pairs<0, false>(S, o, d, t0, k0, c); closest_hit_pairs<PRUNE, false>(S, o, d, t1, k1, c); }
     else { h0 = closest_hit<0, false>(S, o, d, t0, k0, c); closest_hit<PRUNE, false>(S, o, d, t1, k1, c); }
     const bool bad = __float_as_uint(t0) != __float_as_uint(t1) || k0 != k1;
-    const unsigned long long mh = __ballot(h0), mb = __ballot(bad), ma = __ballot(1);
+    // the any-hit rule: an emitter that IS the closest hit must never be excluded by light_bound at its own distance
+    bool emitter = false, violation = false;
+    if (h0 && S.n_lbox != 0u) {
+        const float4 em = S.attrE[k0];
+        emitter = em.x != 0.0f || em.y != 0.0f || em.z != 0.0f;
+        const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        if (emitter && !inv_degenerate(inv)) {
+            Kappa kap = {0.f, 0.f};
+            if (PRUNE == 1) kap = unpack_kappa(pack_kappa(ray_kappa(S, o, d)));
+            violation = prune_far<PRUNE>(light_bound<PRUNE>(S, o, inv, kap), prune_limit<PRUNE>(t0), S.lcoefs, kap);
+        }
+    }
+    const unsigned long long mh = __ballot(h0), mb = __ballot(bad), ma = __ballot(1), me = __ballot(emitter), mv = __ballot(violation);
     if (first_active_lane()) {
         atomicAdd(&out->rays, (unsigned long long)__popcll(ma));
         atomicAdd(&out->hits, (unsigned long long)__popcll(mh));
         if (mb) atomicAdd(&out->mismatches, (unsigned long long)__popcll(mb));
+        if (me) atomicAdd(&out->emitter_hits, (unsigned long long)__popcll(me));
+        if (mv) atomicAdd(&out->anyhit_violations, (unsigned long long)__popcll(mv));
     }
     if (bad) {
         for (int q = 0; q < 16; q++) {                       // claim the first free record
@@ -328,6 +348,8 @@ struct ptx_ctx {
     std::vector<void*> scene_allocs;
     float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};   // of all triangles (ptx_selfcheck_pruning aims rays with it)
     const uint32_t* d_big_slots = nullptr;                     // inorder slots of the largest triangles, by area
+    const uint32_t* d_emit_slots = nullptr;                    // inorder slots of the triangles with a non-zero emission (selfcheck families 8 .. 11)
+    uint32_t n_emit_slots = 0;
     uint32_t n_big_slots = 0;
 
     // params
@@ -1186,13 +1208,17 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         std::partial_sort(big.begin(), big.begin() + keep, big.end(), [&](uint32_t a, uint32_t b) { return area[a] > area[b] || (area[a] == area[b] && a < b); });
         big.resize(keep);
     }
+    std::vector<uint32_t> emit_slots;
+    for (uint32_t k = 0; k < T; k++) if (slot_emits[k]) emit_slots.push_back(k);
+    ctx->n_emit_slots = (uint32_t)emit_slots.size();
+    if (emit_slots.empty()) emit_slots.push_back(0);            // upload() wants a non-empty buffer
     DScene S = {};
     int rc;
     const std::vector<float4> ref_nodes = nodes;      // {min.xyz, miss}, {max.xyz, fc}: becomes layout 8 behind the octant layouts
     repack_nodes(nodes);
     if ((rc = upload(ctx, nodes, &S.nodes)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, aN, &S.attrN)) ||
         (rc = upload(ctx, aC, &S.attrC)) || (rc = upload(ctx, aE, &S.attrE)) || (rc = upload(ctx, light, &S.light)) ||
-        (rc = upload(ctx, big, &ctx->d_big_slots))) {
+        (rc = upload(ctx, big, &ctx->d_big_slots)) || (rc = upload(ctx, emit_slots, &ctx->d_emit_slots))) {
         free_scene(ctx);
         return rc;
     }
@@ -1687,7 +1713,7 @@ extern "C" int ptx_selfcheck_pruning(ptx_ctx* ctx, uint32_t family, uint64_t n_r
     if (!ctx || !out) return PTX_ERR_INVALID;
     PTX_MULTI(ctx, ptx_selfcheck_pruning(ctx->subs[0], family, n_rays, seed, out));
     if (!ctx->have_scene) return fail(ctx, PTX_ERR_STATE, "ptx_selfcheck_pruning: ptx_upload_scene first");
-    if (family > 7) return fail(ctx, PTX_ERR_INVALID, "ptx_selfcheck_pruning: family must be 0 .. 7");
+    if (family > 11) return fail(ctx, PTX_ERR_INVALID, "ptx_selfcheck_pruning: family must be 0 .. 11");
     if (n_rays == 0 || n_rays > (1ull << 37)) return fail(ctx, PTX_ERR_INVALID, "ptx_selfcheck_pruning: n_rays must be in 1 .. 2^37");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_stage(ctx, sizeof(CheckOut));
@@ -1698,6 +1724,9 @@ extern "C" int ptx_selfcheck_pruning(ptx_ctx* ctx, uint32_t family, uint64_t n_r
     HIP_TRY(ctx, hipMemcpy(d_out, &h, sizeof h, hipMemcpyHostToDevice));
     CheckArgs A = {};
     A.n = n_rays; A.seed = seed; A.family = family; A.n_big = ctx->n_big_slots; A.big = ctx->d_big_slots;
+    A.n_emit = ctx->n_emit_slots; A.emit = ctx->d_emit_slots;
+    DScene V = scene_view(ctx);
+    V.n_lbox = ctx->S.n_lbox;                                   // the light boxes are checked whatever the options would make of them
     A.bmin = {ctx->bbox_min[0], ctx->bbox_min[1], ctx->bbox_min[2]};
     A.bmax = {ctx->bbox_max[0], ctx->bbox_max[1], ctx->bbox_max[2]};
     const unsigned long long blocks = (n_rays + 63) / 64;
@@ -1710,16 +1739,17 @@ extern "C" int ptx_selfcheck_pruning(ptx_ctx* ctx, uint32_t family, uint64_t n_r
         B.n = std::min<unsigned long long>(n_rays - done * 64ull, nb * 64ull);
         B.seed = seed + (uint32_t)(done >> 30) * 0x632BE5ABu;
         const bool heuristic = ctx->opt_prune == 2;                 // the pruning rule that option "prune" selects
-        if (pairs && heuristic) hipLaunchKernelGGL((k_selfcheck<2, true>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
-        else if (pairs) hipLaunchKernelGGL((k_selfcheck<1, true>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
-        else if (heuristic) hipLaunchKernelGGL((k_selfcheck<2, false>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
-        else hipLaunchKernelGGL((k_selfcheck<1, false>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, scene_view(ctx), B, d_out);
+        if (pairs && heuristic) hipLaunchKernelGGL((k_selfcheck<2, true>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, V, B, d_out);
+        else if (pairs) hipLaunchKernelGGL((k_selfcheck<1, true>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, V, B, d_out);
+        else if (heuristic) hipLaunchKernelGGL((k_selfcheck<2, false>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, V, B, d_out);
+        else hipLaunchKernelGGL((k_selfcheck<1, false>), dim3((uint32_t)nb), dim3(64), 0, ctx->stream, V, B, d_out);
         HIP_TRY(ctx, hipGetLastError());
         done += nb;
     }
     HIP_TRY(ctx, sync_all(ctx));
     HIP_TRY(ctx, hipMemcpy(&h, d_out, sizeof h, hipMemcpyDeviceToHost));
     out->rays = h.rays; out->hits = h.hits; out->mismatches = h.mismatches;
+    out->emitter_hits = h.emitter_hits; out->anyhit_violations = h.anyhit_violations;
     std::memcpy(out->first, h.first, sizeof h.first);
     std::memcpy(out->first_tri, h.first_tri, sizeof h.first_tri);
     return PTX_OK;

@@ -49,6 +49,35 @@ def test_1e8_adversarial_rays_agree_with_and_without_provable_pruning(ptx, ctx, 
 
 
 @pytest.mark.parametrize("name", SCENES)
+def test_anyhit_light_bound_certificate(ptx, ctx, name):
+    """The any-hit rule for light-visibility rays (option "anyhit") can only go wrong by ending a ray on a blocker although an
+    emitter is hit nearer; for that, light_bound must exclude an emitter at the distance where it IS the closest hit.
+    ptx_selfcheck_pruning checks exactly that for every ray whose unpruned closest hit is an emitter; families 8 .. 11 aim at
+    the emitters (towards points on them, grazing them from afar, skimming their boxes, at their vertices and edges).
+    Provable rule: no violation in >= 5e7 rays per scene.  Margin rule: the violations it does find are counted -- the same
+    caveat as for pruning (rays constructed to graze an emitter), stated in include/ptx.h; none on the rendered frames
+    (tests/test_gpu_parity.py::test_anyhit_light_visibility and every parity test, which run with the rule on)."""
+    s = ptx.load_scene(name)
+    if s.L == 0:
+        pytest.skip("no emitters")
+    ctx.upload_scene(s)
+    for prune in (1, 2):
+        for k, v in dict(pipeline=2, traversal=3, prune=prune).items():
+            ctx.set_option(k, v)
+        emitter_hits = violations = 0
+        for fam in list(range(8, 12)) * 2 + [0, 1]:
+            r = ctx.selfcheck_pruning(fam, 5_000_000, seed=4242 + fam + 100 * prune + emitter_hits % 97)
+            emitter_hits += r["emitter_hits"]
+            violations += r["anyhit_violations"]
+        assert emitter_hits > 1_000_000, (name, prune, emitter_hits)      # the rays really end on emitters
+        if prune == 1:
+            assert violations == 0, (name, violations, emitter_hits)
+        else:
+            print(f"{name}: margin rule, {violations} of {emitter_hits} adversarial emitter hits excluded by the light bound")
+            assert violations < emitter_hits // 1000, (name, violations, emitter_hits)
+
+
+@pytest.mark.parametrize("name", SCENES)
 @pytest.mark.parametrize("pipeline", [0, 2])               # 48-B records + scalar test / pair records + packed math
 def test_reference_tree_and_other_arithmetic(ptx, ctx, name, pipeline):
     ctx.upload_scene(ptx.load_scene(name))
