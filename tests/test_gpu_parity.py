@@ -240,8 +240,9 @@ def test_anyhit_light_visibility(gpu_ctx, ptx, orc, prune):
     like a light of another emission (glsl:353-363) and must never count as a conclusive blocker."""
     far = {0: (50, 50, 50), 1: (50, 50, 50), 40: (20, 30, 40), 41: (20, 30, 40), 100: (5, 0, 0), 77: (0, 9, 0)}
     many = {t: (50, 50, 50) for t in range(0, 122, 5)}
+    most = {t: (7, 7, 7) for t in range(122) if t % 6}                  # > 64 emitters: the chunked pre-merge of the boxes
     cases = [("my_cornell_6", None, (48, 48), 4, 5), ("pixar_room", None, (64, 36), 3, 6), ("bedroom2_v5", None, (48, 27), 3, 4),
-             ("my_cornell_6", far, (40, 40), 3, 5), ("my_cornell_6", many, (40, 40), 3, 4),
+             ("my_cornell_6", far, (40, 40), 3, 5), ("my_cornell_6", many, (40, 40), 3, 4), ("my_cornell_6", most, (32, 32), 2, 4),
              ("my_cornell_6", {60: (-5, 0, 0), 61: (0, 0, -1)}, (40, 40), 4, 5)]
     for name, emit, size, spp, bounces in cases:
         s = ptx.load_scene(name) if emit is None else _with_emitters(ptx, name, emit)
