@@ -256,6 +256,7 @@ def main():
             "config": {"workload": f"{args.config}: {cfg['scene']} {cfg['width']}x{cfg['height']}, {cfg['sample_count']} spp/frame, {cfg['max_path_length']} bounces, one frame per step per GPU",
                        "frames_per_gpu": K, "traversal": {0: "literal (reference tree)", 1: "reference tree + best-t pruning", 2: "leaf-SAH tree", 3: "leaf-SAH tree + best-t pruning"}[3 if args.traversal is None else args.traversal],
                        "pipeline": {0: "one ray per lane", 1: "wave-scheduled, per-lane leaf queues", 2: "wave-scheduled, shared leaf queue"}[2 if args.pipeline is None else args.pipeline],
+                       "light_rays": "exact any-hit termination + blocker cache (library default; same sums and reference ray counters as closest-hit queries)",
                        "parallelism": f"frame-split x{n_gpus} + 1 all-reduce", "allreduce": allreduce_via, "rccl_ranks": ctx.comm_world},
             "roofline": roof,
         }
