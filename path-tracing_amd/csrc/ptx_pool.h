@@ -98,6 +98,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     uint32_t head = 0, tail = 0;                     // wave-uniform queue cursors (free running)
     // work counters as wave totals in scalar registers: every increment is a ballot + popcount in wave-uniform control flow
     uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
+    uint32_t probed = 0xFFFFFFFFu;                   // first slot of the leaf the cache has already queued for the running ray: the walk skips it
     uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     const float4 a = ld16(S.nodes, c_noff), b = ld16(nodes_hi, c_noff);
                     probe = slab_node(ro, inv, a, b, probe_tn) && __float_as_int(b.w) >= 0;
                     probe_item = (uint32_t)__float_as_int(b.w) & 0x00FFFFFFu;
+                    if (probe) probed = probe_item;
                     flags &= ~F_PROBE;
                 }
                 const unsigned long long m = __ballot(probe);     // at most 64 and len < 64 here
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                         // a NaN or partial tn is still a lower bound of the entry distance
                         if (PRUNE == 2) hit = hit && !(tn > limit);
                         if (PRUNE == 1) hit = hit && !(fc < 0 && prune_far<1>(tn, limit, (uint32_t)fc, kappa));   // leaves: at dequeue, with their own coefficients
-                        push = hit && fc >= 0;                       // internal nodes and empty leaves carry -2: nothing to queue
+                        push = hit && fc >= 0 && ((uint32_t)fc & 0x00FFFFFFu) != probed;   // internal nodes and empty leaves carry -2: nothing to queue
                         item = (uint32_t)fc;
                         i = hit ? i + 1u : (uint32_t)miss;
                     }
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 // rays with an infinite or NaN 1/d component walk the reference tree with the selecting slab test (slab_node_ref)
                 const bool deg = inv_degenerate(inv);
                 flags = (flags & ~(F_INF | F_PROBE)) | F_TRAV | (deg ? F_INF : 0);
+                probed = 0xFFFFFFFFu;
                 nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
                 const bool lightray = p.stage() != ST_PATH;
 #if PTX_POOL_CACHE_RESET
