@@ -48,6 +48,9 @@
 #ifndef PTX_POOL_DEFER_CACHED
 #define PTX_POOL_DEFER_CACHED 1  // 1: one pass through shade_step per SHADE phase (cached primary hits wait for the next phase)
 #endif
+#ifndef PTX_POOL_SKIP_PROBED
+#define PTX_POOL_SKIP_PROBED 1   // the walk does not queue the leaf the blocker cache has queued already
+#endif
 #ifndef PTX_POOL_CACHE_RESET
 #define PTX_POOL_CACHE_RESET 0   // 0: the blocker cache survives bounces and samples (63.6 -> 62.7 ms per headline frame: the next bounce is
                                  // often shadowed by the same object); a separate entry for bounce 0 (same point for every sample): no gain
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     uint32_t head = 0, tail = 0;                     // wave-uniform queue cursors (free running)
     // work counters as wave totals in scalar registers: every increment is a ballot + popcount in wave-uniform control flow
     uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
-    uint32_t probed = 0xFFFFFFFFu;                   // first slot of the leaf the cache has already queued for the running ray: the walk skips it
+    uint32_t probed = 0xFFFFFFFFu;                   // fc word of the leaf the cache has already queued for the running ray: the walk skips it
     uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     const float4 a = ld16(S.nodes, c_noff), b = ld16(nodes_hi, c_noff);
                     probe = slab_node(ro, inv, a, b, probe_tn) && __float_as_int(b.w) >= 0;
                     probe_item = (uint32_t)__float_as_int(b.w) & 0x00FFFFFFu;
-                    if (probe) probed = probe_item;
+                    if (probe) probed = (uint32_t)__float_as_int(b.w);     // the leaf's fc word (first | count << 24)
                     flags &= ~F_PROBE;
                 }
                 const unsigned long long m = __ballot(probe);     // at most 64 and len < 64 here
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                         // a NaN or partial tn is still a lower bound of the entry distance
                         if (PRUNE == 2) hit = hit && !(tn > limit);
                         if (PRUNE == 1) hit = hit && !(fc < 0 && prune_far<1>(tn, limit, (uint32_t)fc, kappa));   // leaves: at dequeue, with their own coefficients
-                        push = hit && fc >= 0 && ((uint32_t)fc & 0x00FFFFFFu) != probed;   // internal nodes and empty leaves carry -2: nothing to queue
+                        push = hit && fc >= 0 && (!PTX_POOL_SKIP_PROBED || (uint32_t)fc != probed);   // internal nodes and empty leaves carry -2: nothing to queue
                         item = (uint32_t)fc;
                         i = hit ? i + 1u : (uint32_t)miss;
                     }
