@@ -384,6 +384,7 @@ struct ptx_ctx {
     // counters + timing
     unsigned long long* d_counters = nullptr;
     uint64_t pool_resident[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // pipeline 2: grid size per kernel variant (queried once)
+    bool prune_ok = true;                      // pruning, any-hit and the blocker cache need nested boxes that contain their triangles
     bool pool_ok = true;                       // pipeline 2 needs disjoint leaf ranges (pair records are addressed by first slot)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
     std::vector<hipEvent_t> free_events;
@@ -412,7 +413,7 @@ static hipError_t scratch_for_device(int device, unsigned char** out) {   // `de
 }
 
 // traversal option: bit 0 = best-t pruning, bit 1 = walk the leaf-SAH tree instead of the reference tree
-static inline int prune_mode(const ptx_ctx* c) { return (c->opt_traversal & 1) ? c->opt_prune : 0; }   // the kernels' PRUNE parameter
+static inline int prune_mode(const ptx_ctx* c) { return ((c->opt_traversal & 1) && c->prune_ok) ? c->opt_prune : 0; }   // the kernels' PRUNE parameter
 static inline float __uint_as_float_host(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline DScene scene_view(const ptx_ctx* c) {
     DScene S = c->S;
@@ -662,6 +663,23 @@ static bool ref_tree_is_monotone(const ptx_scene* sc) {
         for (uint32_t c : {L, R})
             for (int k = 0; k < 3; k++)
                 if (!(sc->node_min[3 * (size_t)i + k] <= sc->node_min[3 * (size_t)c + k]) || !(sc->node_max[3 * (size_t)i + k] >= sc->node_max[3 * (size_t)c + k])) return false;
+    }
+    return true;
+}
+
+// Every leaf box contains the vertices of its triangles (f32 comparisons on the uploaded arrays).  Together with
+// ref_tree_is_monotone this is what pruning (a node's box bounds everything beneath it), the any-hit rule and the blocker
+// cache (a leaf whose box is hit is reached by the reference) rest on; every tree classes/bvh.js builds has both properties,
+// but the arrays are legal without them and are then traversed literally.
+static bool leaves_contain_triangles(const ptx_scene* sc) {
+    for (uint32_t i = 0; i < sc->N; i++) {
+        if (sc->node_first[i] == -2) continue;
+        for (int32_t q = 0; q < sc->node_count[i]; q++) {
+            const float* p = sc->coords + 9 * (size_t)sc->inorder_tri[(size_t)sc->node_first[i] + q];
+            for (int v = 0; v < 3; v++)
+                for (int k = 0; k < 3; k++)
+                    if (!(sc->node_min[3 * (size_t)i + k] <= p[3 * v + k]) || !(p[3 * v + k] <= sc->node_max[3 * (size_t)i + k])) return false;
+        }
     }
     return true;
 }
@@ -1256,6 +1274,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     ctx->S = S;
     ctx->n_big_slots = (uint32_t)big.size();
     ctx->pool_ok = disjoint;
+    ctx->prune_ok = ref_tree_is_monotone(sc) && leaves_contain_triangles(sc);
     ctx->have_scene = true;
     ctx->prim_valid = false;
     return PTX_OK;

@@ -268,6 +268,42 @@ def test_anyhit_light_visibility(gpu_ctx, ptx, orc, prune):
     gpu_ctx.set_option("count", 0); gpu_ctx.set_option("prune", 2)
 
 
+def test_boxes_that_do_not_bound(gpu_ctx, ptx, orc):
+    """Legal arrays no builder produces: leaf boxes that do not contain their triangles and an inner box smaller than its
+    children.  The reference walks them literally (glsl:207-249: a leaf is tested iff every box on the way to it is hit), so
+    pruning, the any-hit rule and the blocker cache -- which all assume boxes that bound what is beneath them -- must switch
+    themselves off (ptx_upload_scene checks both properties): every option set still equals the oracle."""
+    import copy
+    for variant in ("leaf", "inner", "both"):
+        s = copy.deepcopy(ptx.load_scene("my_cornell_6"))
+        mn, mx = s.node_min.reshape(-1, 3).copy(), s.node_max.reshape(-1, 3).copy()
+        leaves = np.nonzero(s.node_first != -2)[0]
+        inner = np.nonzero(s.node_first == -2)[0]
+        if variant in ("leaf", "both"):
+            for i in leaves[::3]:
+                mx[i] = mn[i] + 0.35 * (mx[i] - mn[i])                      # the triangles stick out of their leaf's box
+        if variant in ("inner", "both"):
+            for i in inner[1::2]:
+                c = 0.5 * (mn[i] + mx[i]); mn[i] = c + 0.6 * (mn[i] - c); mx[i] = c + 0.6 * (mx[i] - c)   # smaller than its children
+        s.node_min = np.ascontiguousarray(mn.reshape(-1), dtype=np.float32); s.node_max = np.ascontiguousarray(mx.reshape(-1), dtype=np.float32)
+        s.validate()
+        p = ptx.config_params("my_cornell_6", 40, 40, 3, 5)
+        gpu_ctx.upload_scene(s); gpu_ctx.set_params(p)
+        ts = ptx.scene.timestamps(2)
+        want, oc = orc.render_frames(s, p, ts)
+        assert want.max() > 0
+        for pipeline in (0, 1, 2):
+            for traversal in (0, 1, 3):
+                for prune in (1, 2):
+                    for k, v in dict(pipeline=pipeline, traversal=traversal, prune=prune, anyhit=1, memo=1).items():
+                        gpu_ctx.set_option(k, v)
+                    gpu_ctx.reset_accum(); gpu_ctx.reset_counters(); gpu_ctx.render_frames(ts)
+                    assert (bits(gpu_ctx.read_sum()) == bits(want)).all(), (variant, pipeline, traversal, prune)
+                    c = gpu_ctx.counters()
+                    assert c["rays"] == oc["rays"] and c["ray_hits"] == oc["ray_hits"]
+    gpu_ctx.set_option("prune", 2); gpu_ctx.set_option("pipeline", 2); gpu_ctx.set_option("traversal", 3)
+
+
 def test_task_list_shapes(gpu_ctx, ptx, orc):
     """Pipeline 2's task list (tile-major, frame-minor, chunks drawn from a counter): ragged image sizes, frame counts that do
     not divide anything, chunk sizes that are not multiples of a tile -- the sum never changes."""
