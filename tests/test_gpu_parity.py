@@ -244,8 +244,11 @@ def test_anyhit_light_visibility(gpu_ctx, ptx, orc, prune):
     cases = [("my_cornell_6", None, (48, 48), 4, 5), ("pixar_room", None, (64, 36), 3, 6), ("bedroom2_v5", None, (48, 27), 3, 4),
              ("my_cornell_6", far, (40, 40), 3, 5), ("my_cornell_6", many, (40, 40), 3, 4), ("my_cornell_6", most, (32, 32), 2, 4),
              ("my_cornell_6", {60: (-5, 0, 0), 61: (0, 0, -1)}, (40, 40), 4, 5)]
-    for name, emit, size, spp, bounces in cases:
-        s = ptx.load_scene(name) if emit is None else _with_emitters(ptx, name, emit)
+    for name, emit, size, spp, bounces in cases + [("my_cornell_6", "dark light", (40, 40), 3, 5)]:
+        s = ptx.load_scene(name) if emit is None else _with_emitters(ptx, name, emit if isinstance(emit, dict) else {})
+        if emit == "dark light":                   # the light list names a triangle of emission (0,0,0): a blocker then compares EQUAL to the light (glsl:359) and the
+            # attempt counts as visible -- shade_step still makes that comparison, the rule only supplies "emission (0,0,0)"
+            s.light_tri = np.ascontiguousarray(np.append(s.light_tri, 70), dtype=np.int32); s.L = int(s.light_tri.size); s.validate()
         p = ptx.config_params(name, *size, spp, bounces)
         gpu_ctx.upload_scene(s); gpu_ctx.set_params(p)
         ts = ptx.scene.timestamps(2)
