@@ -25,6 +25,12 @@ def test_node_cli_matches_ctypes_and_oracle(ptx, orc, gpu_ctx, tmp_path):
     want, _ = orc.render_frames(s, p, ptx.scene.timestamps(nfr))
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
     assert open(png, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    # the traversal switches of the CLI: provable pruning rule / the reference's literal traversal give the same sum
+    for extra in (["--prune", "1"], ["--traversal", "0"]):
+        subprocess.check_call(["node", os.path.join(ROOT, "path-tracing_amd", "host", "main.js"), "--scene", os.path.join(scenes, name + ".ptxs"),
+                               "--camera-json", os.path.join(scenes, name + ".json"), "--width", str(w), "--height", str(h), "--frames", str(nfr),
+                               "--spp", str(spp), "--bounces", str(b), "--dump-sum", out] + extra)
+        assert (np.fromfile(out, dtype=np.float32).reshape(h, w, 3).view(np.uint32) == want.view(np.uint32)).all(), extra
 
 
 @pytest.mark.gpu
