@@ -84,7 +84,9 @@ typedef struct ptx_counters {
     uint64_t light_attempts; /* iterations of sample_random_light's loop (glsl:372)                      */
     uint64_t pixel_frames;   /* (pixel, frame) results accumulated                                       */
     uint64_t kernel_launches;/* launches of the path-tracing kernel                                      */
-    double kernel_ms;        /* HIP-event time of those launches, summed (valid after ptx_synchronize)   */
+    double kernel_ms;        /* HIP-event time of those launches, summed (valid after ptx_synchronize).  With option
+                                "overlap" successive calls run on two streams and their spans overlap: the sum then
+                                exceeds the wall time of a loop of small calls (one call = one span: exact)        */
     uint64_t diag[12];       /* SIMT-efficiency diagnostics, only with option "count" = 1: lane-iterations that did work and
                                 64 x wave-iterations for {node walk, triangle tests, traversal calls}: useful, slots pairs; then shader
                                 cycles and wave-iterations per phase {walk, tri, shade} of pipelines 1 and 2 */
@@ -171,15 +173,20 @@ int ptx_set_option(ptx_ctx *ctx, const char *key, int64_t value);
  * for the float accumulation: the running mean sum/frames_done equals the reference's mix(prev, cur, 1/(frameNumber+1))
  * chain (glsl:537-540) without its RGBA8 rounding; with option "compat_rgba8" it is the frameNumber of that chain.  Asynchronous: work is queued on the context's stream. */
 int ptx_render_frames(ptx_ctx *ctx, const int32_t *timestamps, uint32_t n_frames, uint32_t first_frame_number);
-/* The same rendering for callers that cannot allocate.  No counterpart in the reference: it is for code under HIP graph
- * capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels and bit-identical results
+/* The same rendering for callers that cannot allocate.  No counterpart in the reference: it is for tight serving loops and
+ * harnesses that forbid hipMalloc.  Same arguments, same kernels and bit-identical results
  * as ptx_render_frames, but every intermediate (the frame buffers of a batch, its timestamps, the task counter) lives in a
  * file-scope static __device__ array of 64 MiB + 512 B per GPU (held until the process ends) instead of library
- * allocations: the call makes no hipMalloc / hipFree / hipEventCreate and no host-to-device copy.  Limit: width * height
+ * allocations: the call makes no hipMalloc / hipFree / hipEventCreate and no host-to-device copy.  It is NOT capturable
+ * into a HIP graph: the work goes to the library's own streams, and the first call per camera (or after a change of option
+ * "traversal" / "prune") fills the per-pixel primary-hit cache and waits for it (one hipStreamSynchronize; the first use
+ * of a kernel variant also runs an occupancy query).  Limit: width * height
  * <= 4 194 304 pixels (64 MiB / 16 B; frames are batched to fit), else PTX_ERR_INVALID with a message.  Scene and params
  * must already be set (ptx_upload_scene / ptx_set_params allocate; this call does not); option "compat_rgba8" only if an
  * earlier ptx_render_frames created its 8-bit targets.  The launches are not event-timed (ptx_counters.kernel_ms does
- * not include them).  All contexts on one GPU share that GPU's array: calls that overlap on one GPU race. */
+ * not include them).  All contexts on one GPU share that GPU's array, one at a time: the calling context owns it until it
+ * has synchronised (ptx_synchronize, any read-back) or is destroyed, and a call from another context on that GPU meanwhile
+ * fails with PTX_ERR_STATE instead of racing. */
 int ptx_render_frames_noalloc(ptx_ctx *ctx, const int32_t *timestamps, uint32_t n_frames, uint32_t first_frame_number);
 int ptx_synchronize(ptx_ctx *ctx);
 /* Replaces gl.clear of the ping-pong targets (main.js:326-327) / starting a new progressive render. */

@@ -439,11 +439,28 @@ static int fail(ptx_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// The static scratch of a GPU has ONE user at a time: the context whose ptx_render_frames_noalloc work may still be running
+// on it.  Claimed by that entry point, released when the context has synchronised (sync_all) or is destroyed; a second
+// context that asks meanwhile gets PTX_ERR_STATE instead of a race.
+static const ptx_ctx* g_scratch_owner[PTX_MAX_DEVICES] = {};
+static bool scratch_claim(const ptx_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (ctx->device < 0 || ctx->device >= PTX_MAX_DEVICES) return false;
+    if (g_scratch_owner[ctx->device] && g_scratch_owner[ctx->device] != ctx) return false;
+    g_scratch_owner[ctx->device] = ctx;
+    return true;
+}
+static void scratch_release(const ptx_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (ctx->device >= 0 && ctx->device < PTX_MAX_DEVICES && g_scratch_owner[ctx->device] == ctx) g_scratch_owner[ctx->device] = nullptr;
+}
+
 // both launch slots idle (device current)
 static hipError_t sync_all(ptx_ctx* ctx) {
     hipError_t e = hipSuccess;
     for (int k = 0; k < 2; k++)
         if (ctx->slot[k].stream) { const hipError_t ek = hipStreamSynchronize(ctx->slot[k].stream); if (e == hipSuccess) e = ek; ctx->slot[k].busy = false; }
+    if (e == hipSuccess) scratch_release(ctx);
     return e;
 }
 
@@ -557,6 +574,7 @@ extern "C" void ptx_destroy(ptx_ctx* ctx) {
     if (!ctx->subs.empty()) { multi_destroy(ctx); return; }
     (void)hipSetDevice(ctx->device);
     (void)sync_all(ctx);
+    scratch_release(ctx);
     comm_release(ctx);
     free_scene(ctx);
     free_params_buffers(ctx);
@@ -1351,6 +1369,7 @@ static int ensure_primary(ptx_ctx* ctx, float4* d_dirs) {
     const uint32_t tiles = ((ctx->P.W + 7) / 8) * ((ctx->P.H + 7) / 8);
     // primary rays are always traced WITHOUT pruning (2 M rays once per camera: 0.3 ms): the per-pixel primary-hit cache, and
     // with it every primary hit of every frame, is the unpruned closest hit whatever option "prune" says
+    HIP_TRY(ctx, sync_all(ctx));                                // a path tracer still running on either launch slot reads the cache
     hipLaunchKernelGGL(k_primary<0>, dim3(tiles), dim3(64), 0, ctx->stream, scene_view(ctx), ctx->P, ctx->d_prim_t, ctx->d_prim_tri, d_dirs);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));            // once per camera: both launch slots read the cache
@@ -1567,8 +1586,11 @@ extern "C" int ptx_render_frames_noalloc(ptx_ctx* ctx, const int32_t* timestamps
         return fail(ctx, PTX_ERR_STATE, "ptx_render_frames_noalloc: option compat_rgba8 needs its 8-bit targets, which only ptx_render_frames allocates");
     if (n_frames == 0) return PTX_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_primary(ctx, nullptr);
+    int rc = ensure_primary(ctx, nullptr);                                    // allocates nothing; synchronises once per camera
     if (rc) return rc;
+    if (!scratch_claim(ctx))
+        return fail(ctx, PTX_ERR_STATE, "ptx_render_frames_noalloc: the static scratch of device " + std::to_string(ctx->device) +
+                                            " is in use by another context; ptx_synchronize that context first");
     unsigned char* const base = ctx->d_scratch;                               // the device address, never the symbol's name
     int32_t* const d_ts = (int32_t*)(base + PTX_SCRATCH_TS_OFFSET);
     LaunchSlot& sl = ctx->slot[0];                                            // one scratch per GPU: always slot 0, behind slot 1's work
@@ -1904,7 +1926,10 @@ const RcclApi* rccl_api(std::string* err) {
     void* h = nullptr;
     std::string tried;
     const char* env = getenv("PTX_RCCL_LIB");
-    if (env && *env) { h = dlopen(env, RTLD_NOW | RTLD_GLOBAL); g_rccl.path = env; if (!h) tried += std::string(env) + ": " + dlerror() + "; "; }
+    if (env && *env) {       // an explicit choice is honoured or fails: no silent fall-through to another copy
+        h = dlopen(env, RTLD_NOW | RTLD_GLOBAL); g_rccl.path = env;
+        if (!h) { *err = std::string("cannot load librccl from PTX_RCCL_LIB (") + env + ": " + dlerror() + ")"; return nullptr; }
+    }
     // a copy that is already mapped (torch's librccl.so has no SONAME, ROCm's is librccl.so.1)
     for (const char* name : {"librccl.so", "librccl.so.1"})
         if (!h && (h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) g_rccl.path = std::string(name) + " (already mapped)";
@@ -2121,12 +2146,17 @@ static int multi_reduce(ptx_ctx* m) {
         HIP_TRY(m, hipSetDevice(s->device));
         HIP_TRY(m, hipMalloc(&s->d_total, npix * sizeof(float4)));
     }
+    // Every sub renders on two alternating launch slots (streams), and the reduction below is queued on slot 0's stream
+    // only: BOTH slots of EVERY sub (sub 0 included) must have finished their accumulates before d_accum is read.
+    for (ptx_ctx* s : m->subs) {
+        HIP_TRY(m, hipSetDevice(s->device));
+        HIP_TRY(m, sync_all(s));
+    }
     if (m->same_device) {
         SumSrcs srcs = {};
         srcs.n = (int)G;
         for (size_t g = 0; g < G; g++) srcs.p[g] = m->subs[g]->d_accum;
         HIP_TRY(m, hipSetDevice(s0->device));
-        for (size_t g = 1; g < G; g++) HIP_TRY(m, sync_all(m->subs[g]));    // their frames are in their buffers
         hipLaunchKernelGGL(k_sum_accums, dim3((uint32_t)((npix + 255) / 256)), dim3(256), 0, s0->stream, s0->d_total, srcs, (uint32_t)npix);
         HIP_TRY(m, hipGetLastError());
         HIP_TRY(m, sync_all(s0));

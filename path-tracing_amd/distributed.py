@@ -27,14 +27,33 @@ def allreduce_sum(tensor, group=None):
 
 def init_library_comm(ctx, group=None):
     """Creates the library's RCCL communicator on `ctx` for the ranks of the torch.distributed group: rank 0 draws the id
-    (ptx_comm_unique_id), the group broadcasts its 128 bytes, every rank calls ptx_comm_init.  Returns the rank count RCCL
-    reports.  Collective: every rank of the group must call it."""
+    (ptx_comm_unique_id), the group hands its 128 bytes round, every rank calls ptx_comm_init.  Returns the rank count RCCL
+    reports.  Collective: every rank of the group must call it, and every rank gets the same outcome -- if librccl cannot
+    be loaded or the id cannot be drawn on ANY rank, all ranks raise the same PtxError after the exchange (nobody is left
+    waiting in a broadcast or inside ncclCommInitRank), and a failure inside ptx_comm_init on one rank is raised on all."""
     import torch.distributed as dist
     from . import binding
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    box = [binding.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    ctx.comm_init(box[0], rank, world)
+    # every rank proves that it can load librccl and draw an id (cheap); rank 0's id is the one that is used
+    try:
+        mine = (binding.comm_unique_id(), "")
+    except Exception as e:                                  # noqa: BLE001 - travels to the other ranks
+        mine = (None, f"rank {rank}: {e}")
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine, group=group)
+    bad = [why for uid, why in everyone if uid is None]
+    if bad:
+        raise binding.PtxError(binding.PTX_ERR_HIP, "init_library_comm: no RCCL communicator on any rank because " + "; ".join(bad))
+    err = ""
+    try:
+        ctx.comm_init(everyone[0][0], rank, world)
+    except Exception as e:                                  # noqa: BLE001
+        err = f"rank {rank}: {e}"
+    errs = [None] * world
+    dist.all_gather_object(errs, err, group=group)
+    errs = [e for e in errs if e]
+    if errs:
+        raise binding.PtxError(binding.PTX_ERR_HIP, "init_library_comm: ptx_comm_init failed: " + "; ".join(errs))
     return ctx.comm_world
 
 

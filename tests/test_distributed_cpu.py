@@ -88,3 +88,37 @@ def test_render_frames_distributed_two_ranks_one_gpu(ptx, gpu_ctx, tmp_path):
     assert np.abs(a - want).max() <= 4 * np.finfo(np.float32).eps * n_frames   # float-add association only
     seen = np.load(tmp_path / "seen0.npy")
     assert [int(x) for x in seen[:, 0]] == [4, 5] and seen[0, 1] < seen[1, 1]  # previews: 2 + 2 frames, then all 5
+
+
+def _comm_fail_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if rank == 0:
+        os.environ["PTX_RCCL_LIB"] = "/nonexistent/librccl.so"      # rank 0 cannot load RCCL; rank 1 may or may not (no GPU here)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ptx_import
+    m = ptx_import.load()
+
+    class NoCtx:                                                     # never reached: the id exchange fails first
+        def comm_init(self, *a):
+            raise AssertionError("ptx_comm_init must not be called when a rank has no RCCL")
+    msg = "no error"
+    try:
+        m.distributed.init_library_comm(NoCtx())
+    except m.PtxError as e:
+        msg = str(e)
+    # the collective that bench.py runs next must still line up on both ranks
+    flag = torch.tensor([rank + 1], dtype=torch.int32)
+    dist.all_reduce(flag)
+    open(os.path.join(out_dir, f"r{rank}.txt"), "w").write(f"{int(flag.item())}|{msg}")
+    dist.destroy_process_group()
+
+
+def test_init_library_comm_fails_on_every_rank_together(tmp_path):
+    """rank 0 raising before the broadcast left the other ranks in it.  Now every rank raises the same error."""
+    port = 29500 + (os.getpid() + 13) % 2000
+    mp.spawn(_comm_fail_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (open(tmp_path / f"r{k}.txt").read().split("|", 1) for k in (0, 1))
+    assert r0[0] == r1[0] == "3"                                     # the following all-reduce matched up
+    assert "rank 0" in r0[1] and "PTX_RCCL_LIB" in r0[1]
+    assert r0[1] == r1[1]

@@ -130,3 +130,39 @@ def test_library_rccl_communicator_world_of_one(ptx):
         assert (bits(ctx.read_sum()) == bits(before)).all()
         with pytest.raises(ptx.PtxError):
             ctx.comm_init(uid, 1, 1)                    # rank out of range
+
+
+def test_read_after_two_unsynchronised_calls_on_a_large_frame(ptx):
+    """Every sub alternates two launch slots (streams); the reduction on read must wait for BOTH slots of EVERY sub.  Two
+    render_frames calls without a read in between on a frame large enough that sub 0's second call (slot 1) is still running
+    when the host reaches the read; equals the definition bit for bit (round-2 review: multi_reduce only waited for slot 0)."""
+    name, w, h, spp, b = "pixar_room", 1920, 1080, 2, 4
+    ts = ptx.scene.timestamps(4)
+
+    def ctx_for(devices):
+        c = ptx.Context(devices)
+        c.upload_scene(ptx.load_scene(name))
+        c.set_params(ptx.config_params(name, w, h, spp, b))
+        return c
+
+    frames = []
+    with ctx_for(0) as one:
+        for t in ts:
+            one.reset_accum()
+            one.render_frames([t])
+            frames.append(one.read_sum())
+    with ctx_for([0, 0]) as multi:
+        for rep in range(3):                         # repeated: the hole was a timing matter
+            multi.reset_accum()
+            multi.render_frames(ts[:2])              # frame 0 -> sub 0 (slot 0), frame 1 -> sub 1 (slot 0)
+            multi.render_frames(ts[2:], first_frame_number=2)   # frame 2 -> sub 0 (slot 1), frame 3 -> sub 1 (slot 1)
+            got = multi.read_sum()
+            want = (frames[0] + frames[2]) + (frames[1] + frames[3])
+            assert (bits(got) == bits(want)).all()
+        # one-frame calls all land on sub 0 and alternate its two slots
+        multi.reset_accum()
+        for k, t in enumerate(ts):
+            multi.render_frames([t], first_frame_number=k)
+        got = multi.read_sum()
+        want = ((frames[0] + frames[1]) + frames[2]) + frames[3]
+        assert (bits(got) == bits(want)).all()

@@ -50,3 +50,37 @@ def test_noalloc_rejects_images_beyond_the_scratch(ptx):
         ctx.render_frames_noalloc([1000, 1001])
         ctx.synchronize()
         assert ctx.frames_done == 2
+
+
+def test_noalloc_scratch_has_one_owner_at_a_time(ptx):
+    # two contexts on one GPU share that GPU's static scratch: the second caller is refused until the first has synchronised
+    ts = ptx.scene.timestamps(2)
+    with ptx.Context(0) as a, ptx.Context(0) as b:
+        for c in (a, b):
+            c.upload_scene(ptx.load_scene("my_cornell_6"))
+            c.set_params(ptx.config_params("my_cornell_6", 64, 48, 2, 3))
+        a.render_frames_noalloc(ts)                                         # queued, not synchronised: a owns the scratch
+        with pytest.raises(ptx.PtxError) as e:
+            b.render_frames_noalloc(ts)
+        assert e.value.status == ptx.binding.PTX_ERR_STATE and "in use by another context" in str(e.value)
+        a.synchronize()
+        b.render_frames_noalloc(ts)                                         # released by the synchronisation
+        assert (bits(a.read_sum()) == bits(b.read_sum())).all()
+        a.render_frames_noalloc(ts)                                         # b's read-back synchronised b: free again
+        a.synchronize()
+
+
+def test_noalloc_leaves_free_device_memory_unchanged(ptx):
+    import torch
+    ts = ptx.scene.timestamps(3)
+    with ptx.Context(0) as ctx:
+        ctx.upload_scene(ptx.load_scene("my_cornell_6"))
+        ctx.set_params(ptx.config_params("my_cornell_6", 256, 256, 2, 3))
+        ctx.render_frames_noalloc(ts)                                       # warm-up: primary-hit cache, occupancy query, code objects
+        ctx.synchronize()
+        free0, _ = torch.cuda.mem_get_info(0)
+        ctx.render_frames_noalloc(ts)
+        free1, _ = torch.cuda.mem_get_info(0)                               # while the work is still queued / running
+        ctx.synchronize()
+        free2, _ = torch.cuda.mem_get_info(0)
+        assert free0 == free1 == free2
