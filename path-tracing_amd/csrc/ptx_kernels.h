@@ -39,6 +39,9 @@ struct DScene {
     uint32_t oct_stride;   // bytes between the 8 direction-octant layouts of `nodes` (0: a single layout)
     uint32_t ref_base;     // byte offset in `nodes` of the reference tree itself (layout 8 behind the octant layouts; 0 when
                            // `nodes` IS the reference tree): rays with an infinite 1/d component walk it (slab_node_ref)
+    uint32_t hot_k;        // pipeline 2 only.  > 0: `nodes` holds the hot-first layouts with EXPLICIT links (inner node: fc =
+                           // 0x80000000 | index of its first child; after a leaf, hit or not, the walk goes to the miss link) and
+                           // the first hot_k records of each octant layout are read from LDS.  0: pre-order layouts, hit -> i + 1
     V3 center;             // centre of the scene's bounding box                         } provable pruning: ray_kappa()
     float two_rs, m_cap;   // twice its half-diagonal; largest M_ray the coefficients hold for }
     int n_cls;             // dominant plane normals of the scene's large flat triangles ("classes", unit vectors)

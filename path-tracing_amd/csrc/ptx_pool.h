@@ -55,25 +55,54 @@
 #define PTX_POOL_CACHE_RESET 0   // 0: the blocker cache survives bounces and samples (63.6 -> 62.7 ms per headline frame: the next bounce is
                                  // often shadowed by the same object); a separate entry for bounce 0 (same point for every sample): no gain
 #endif
+#ifndef PTX_POOL_WAVES
+#define PTX_POOL_WAVES 16         // waves per workgroup.  One workgroup per CU: its waves share the LDS copy of the hot node records;
+                                  // everything else in LDS (path state, keys, leaf queue) is private to a wave, and after the one
+                                  // barrier behind the copy the waves never synchronise again
+#endif
+#ifndef PTX_POOL_HOTK
+#define PTX_POOL_HOTK 112         // hot node records per octant layout staged in LDS (8 layouts x 32 B each): 16 x 8 KB + 28 KB = 156 KB of the CU's 160 KB
+#endif
 #ifndef PTX_POOL_MIN_WAVES
-#define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
+#define PTX_POOL_MIN_WAVES (PTX_POOL_WAVES / 4)   // waves per SIMD the register allocation aims for (4 -> 128 VGPRs)
 #endif
 
 namespace ptx {
 
+#ifdef PTX_HEAT
+__device__ unsigned int g_heat[1u << 20];    // diagnostic build only: node-visit histogram over all layouts
+#endif
+
 #define PTX_POOL_KEY_NONE ((unsigned long long)0x7e967699u << 32 | 0xFFFFFFFFull)   // bits(1.0e38f) << 32 | 0xFFFFFFFF: "no hit yet"
 
 template <int PRUNE, bool MEMO, bool COUNT>
-__global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
+__global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
                                                     const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
                                                     float4* __restrict__ fb, uint32_t n_frames, uint32_t chunk,
                                                     uint32_t* __restrict__ task_counter, unsigned long long* counters) {
-    __shared__ float lds[PW_C_SAMPLES * 64];         // path state only (25 words per lane); work counters live in scalar registers
-    __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
-    __shared__ uint2 queue[PTX_POOL_QCAP];
-    __shared__ uint32_t kap[64];                     // PRUNE = 1: packed kappa pair of the lane's ray (ray_kappa), read by whoever tests its leaves
-    __shared__ float tlm[64];                        // PRUNE != 0: light_bound of the lane's ray if it is a light-visibility ray, else -3e38
-    const uint32_t lane = threadIdx.x;
+    // per wave (private; `wv` selects the wave's slice):
+    __shared__ float lds_all[PTX_POOL_WAVES][PW_C_SAMPLES * 64];         // path state only (25 words per lane); work counters live in scalar registers
+    __shared__ unsigned long long keys_all[PTX_POOL_WAVES][64];          // best (t, slot) of the lane's ray
+    __shared__ uint2 queue_all[PTX_POOL_WAVES][PTX_POOL_QCAP];
+    __shared__ uint32_t kap_all[PRUNE == 1 ? PTX_POOL_WAVES : 1][64];    // PRUNE = 1: packed kappa pair of the lane's ray (ray_kappa), read by whoever tests its leaves
+    __shared__ float tlm_all[PTX_POOL_WAVES][64];                        // PRUNE != 0: light_bound of the lane's ray if it is a light-visibility ray, else -3e38
+    // shared by the workgroup, read-only after the barrier: the hot_k hottest node records of each octant layout
+    __shared__ float4 hot[PRUNE == 1 ? 2 : 8 * PTX_POOL_HOTK * 2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = PTX_POOL_WAVES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
+    float* const lds = lds_all[wv];
+    unsigned long long* const keys = keys_all[wv];
+    uint2* const queue = queue_all[wv];
+    uint32_t* const kap = kap_all[PRUNE == 1 ? wv : 0];
+    float* const tlm = tlm_all[wv];
+    if (PRUNE != 1 && S.hot_k != 0u) {               // hot records: layout o, record r, half h  ->  hot[(o * hot_k + r) * 2 + h]
+        const uint32_t per = S.hot_k * 2u;
+        for (uint32_t q = threadIdx.x; q < 8u * per; q += 64u * PTX_POOL_WAVES) {
+            const uint32_t o = q / per, r = q - o * per;
+            hot[q] = ld16(S.nodes, o * S.oct_stride + r * 16u);
+        }
+    }
+    if (PTX_POOL_WAVES > 1) __syncthreads();         // the only barrier: from here on every wave runs on its own
     const LdsLane L{lds + lane};
     const uint32_t npix = P.W * P.H;
     const uint32_t tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
@@ -103,6 +132,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
     uint32_t probed = 0xFFFFFFFFu;                   // fc word of the leaf the cache has already queued for the running ray: the walk skips it
     uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
+    uint32_t hot_off = 0, hot_lim = 0;               // hot_k > 0: LDS byte offset of the ray's octant layout; records below hot_lim are read from LDS
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
 
@@ -162,7 +192,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             }
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
             const bool ordered = S.oct_stride != 0u && __ballot(w0 && (flags & F_INF)) == 0ull;
-            auto walk = [&](auto MODE) {
+            auto walk = [&](auto MODE, auto LINKS) {
+                constexpr bool HOT = decltype(LINKS)::value;      // hot-first layouts: explicit links, the hottest records in LDS
                 bool w = w0;                                      // trav && i < N, carried from one step to the next
 #pragma nounroll
                 for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
@@ -171,11 +202,20 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     uint32_t item = 0;
                     float tn = 0.f;
                     if (w) {
-                        const float4 a = ld16(S.nodes, nbase + (i << 5));
-                        const float4 b = ld16(nodes_hi, nbase + (i << 5));
+                        float4 a, b;
+                        if (HOT && i < hot_lim) {
+                            const float4* h = (const float4*)((const char*)hot + hot_off + (i << 5));
+                            a = h[0]; b = h[1];
+                        } else {
+                            a = ld16(S.nodes, nbase + (i << 5));
+                            b = ld16(nodes_hi, nbase + (i << 5));
+                        }
                         int miss = __float_as_int(b.z), fc = __float_as_int(b.w);
                         asm volatile("" : "+v"(miss), "+v"(fc));     // keep the links in the record's two loads (no third, dependent one)
                         if (COUNT) cnt_nodes++;
+#ifdef PTX_HEAT
+                        atomicAdd(&g_heat[(nbase >> 5) + i], 1u);   // diagnostic build only (tools/dbg/heat.py): visits per node record
+#endif
                         // MODE 0: every walking lane takes the entry-first shortcut; 1: lanes with an infinite 1/d component walk
                         // the reference tree with the selecting test (second-operand NaN rule), the others stay entry-first;
                         // 2: single-layout views (the reference tree for everyone): selecting tests only
@@ -190,7 +230,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                         if (PRUNE == 1) hit = hit && !(fc < 0 && prune_far<1>(tn, limit, (uint32_t)fc, kappa));   // leaves: at dequeue, with their own coefficients
                         push = hit && fc >= 0 && (!PTX_POOL_SKIP_PROBED || (uint32_t)fc != probed);   // internal nodes and empty leaves carry -2: nothing to queue
                         item = (uint32_t)fc;
-                        i = hit ? i + 1u : (uint32_t)miss;
+                        if (HOT) i = (hit && fc < 0) ? ((uint32_t)fc & 0x7FFFFFFFu) : (uint32_t)miss;   // after a leaf the walk goes on at its miss link
+                        else i = hit ? i + 1u : (uint32_t)miss;
                     }
                     const unsigned long long m = __ballot(push);
                     if (push) {
@@ -204,9 +245,12 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     if (__popcll(__ballot(w)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
                 }
             };
-            if (ordered) walk(std::integral_constant<int, 0>{});
-            else if (S.oct_stride != 0u) walk(std::integral_constant<int, 1>{});
-            else walk(std::integral_constant<int, 2>{});
+            if (PRUNE != 1 && S.hot_k != 0u) {
+                if (ordered) walk(std::integral_constant<int, 0>{}, std::true_type{});
+                else walk(std::integral_constant<int, 1>{}, std::true_type{});
+            } else if (ordered) walk(std::integral_constant<int, 0>{}, std::false_type{});
+            else if (S.oct_stride != 0u) walk(std::integral_constant<int, 1>{}, std::false_type{});
+            else walk(std::integral_constant<int, 2>{}, std::false_type{});
         } else if (phase == 1) {
             const uint32_t n = min(len, 64u);
             const bool has = lane < n;
@@ -386,7 +430,10 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 const bool deg = inv_degenerate(inv);
                 flags = (flags & ~(F_INF | F_PROBE)) | F_TRAV | (deg ? F_INF : 0);
                 probed = 0xFFFFFFFFu;
-                nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
+                const uint32_t oc = octant(rd);
+                nbase = deg ? S.ref_base : oc * S.oct_stride;
+                hot_off = oc * (S.hot_k << 5);
+                hot_lim = deg ? 0u : S.hot_k;                 // the reference tree (layout 8) is not staged
                 const bool lightray = p.stage() != ST_PATH;
 #if PTX_POOL_CACHE_RESET
                 if (!lightray) c_noff = 0xFFFFFFFFu;         // 1: the cache belongs to the attempts of one bounce
