@@ -1938,6 +1938,7 @@ extern "C" int ptx_get_counters(ptx_ctx* ctx, ptx_counters* out) {
     out->kernel_launches = ctx->kernel_launches;
     out->kernel_ms = ctx->kernel_ms;
     for (int k = 0; k < 12; k++) out->diag[k] = h[CNT_WALK_USEFUL + k];
+    for (int k = 0; k < 4; k++) out->diag2[k] = h[CNT_TAIL_PASSES + k];
     return PTX_OK;
 }
 
@@ -2345,6 +2346,7 @@ static int multi_get_counters(ptx_ctx* m, ptx_counters* out) {
         out->kernel_launches += c.kernel_launches;
         out->kernel_ms = std::max(out->kernel_ms, c.kernel_ms);       // the devices run side by side: the busiest one's time
         for (int k = 0; k < 12; k++) out->diag[k] += c.diag[k];
+        for (int k = 0; k < 4; k++) out->diag2[k] += c.diag2[k];
     }
     return PTX_OK;
 }

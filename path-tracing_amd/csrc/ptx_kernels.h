@@ -61,7 +61,8 @@ struct DParams {
 
 // device-side work counters (u64), one block of these per context
 enum { CNT_SAMPLES = 0, CNT_RAYS, CNT_RAYS_TRACED, CNT_NODE_VISITS, CNT_TRI_TESTS, CNT_RAY_HITS, CNT_LIGHT_ATTEMPTS, CNT_PIXEL_FRAMES,
-       CNT_WALK_USEFUL, CNT_WALK_SLOTS, CNT_TRI_USEFUL, CNT_TRI_SLOTS, CNT_TRACE_USEFUL, CNT_TRACE_SLOTS, CNT_CYC_WALK, CNT_CYC_TRI, CNT_CYC_SHADE, CNT_IT_WALK, CNT_IT_TRI, CNT_IT_SHADE, CNT_NUM };
+       CNT_WALK_USEFUL, CNT_WALK_SLOTS, CNT_TRI_USEFUL, CNT_TRI_SLOTS, CNT_TRACE_USEFUL, CNT_TRACE_SLOTS, CNT_CYC_WALK, CNT_CYC_TRI, CNT_CYC_SHADE, CNT_IT_WALK, CNT_IT_TRI, CNT_IT_SHADE,
+       CNT_TAIL_PASSES, CNT_TAILS, CNT_SPINS, CNT_CYC_SPIN, CNT_NUM };
 
 struct LocalCnt {
     uint32_t samples, rays, rays_traced, node_visits, tri_tests, ray_hits, light_attempts;

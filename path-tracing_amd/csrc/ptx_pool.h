@@ -61,7 +61,10 @@
                                   // barrier behind the copy the waves never synchronise again
 #endif
 #ifndef PTX_POOL_HOTK
-#define PTX_POOL_HOTK 112         // hot node records per octant layout staged in LDS (8 layouts x 32 B each): 16 x 8 KB + 28 KB = 156 KB of the CU's 160 KB
+#define PTX_POOL_HOTK 64          // hot node records per octant layout staged in LDS (8 layouts x 32 B each = 16 KB)
+#endif
+#ifndef PTX_POOL_TAIL_BATCH
+#define PTX_POOL_TAIL_BATCH 64    // pending tails of the workgroup at which a wave stops for a TAIL pass
 #endif
 #ifndef PTX_POOL_MIN_WAVES
 #define PTX_POOL_MIN_WAVES (PTX_POOL_WAVES / 4)   // waves per SIMD the register allocation aims for (4 -> 128 VGPRs)
@@ -88,6 +91,10 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
     __shared__ float tlm_all[PTX_POOL_WAVES][64];                        // PRUNE != 0: light_bound of the lane's ray if it is a light-visibility ray, else -3e38
     // shared by the workgroup, read-only after the barrier: the hot_k hottest node records of each octant layout
     __shared__ float4 hot[PRUNE == 1 ? 2 : 8 * PTX_POOL_HOTK * 2];
+    // TAIL requests of the workgroup: bit l of tail_req[w] = the path of lane l of wave w waits for shade_tail (its state is in
+    // that wave's LDS slice); bit l of tail_done[w] = it has been run.  tail_ctl = {requests pending, gather lock}
+    __shared__ unsigned long long tail_req[PTX_POOL_WAVES], tail_done[PTX_POOL_WAVES];
+    __shared__ uint32_t tail_ctl[2], tail_tmp[64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = PTX_POOL_WAVES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
     float* const lds = lds_all[wv];
@@ -102,7 +109,9 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
             hot[q] = ld16(S.nodes, o * S.oct_stride + r * 16u);
         }
     }
-    if (PTX_POOL_WAVES > 1) __syncthreads();         // the only barrier: from here on every wave runs on its own
+    if (threadIdx.x < (uint32_t)PTX_POOL_WAVES) { tail_req[threadIdx.x] = 0ull; tail_done[threadIdx.x] = 0ull; }
+    if (threadIdx.x < 2u) tail_ctl[threadIdx.x] = 0u;
+    __syncthreads();                                 // the only barrier: from here on every wave runs on its own
     const LdsLane L{lds + lane};
     const uint32_t npix = P.W * P.H;
     const uint32_t tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
     auto below = [](unsigned long long m) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
 
     keys[lane] = PTX_POOL_KEY_NONE;
-    unsigned long long cyc[3] = {0, 0, 0}, its[3] = {0, 0, 0};
+    unsigned long long cyc[3] = {0, 0, 0}, its[3] = {0, 0, 0}, n_tailp = 0, n_tails = 0, n_spin = 0, cyc_spin = 0;   // COUNT only
     uint32_t cnt_nodes = 0, cnt_tris = 0, d_walk = 0, d_tri = 0, d_shade = 0, d_walk_s = 0, d_tri_s = 0, d_shade_s = 0;   // COUNT only
 
     int flags = F_ALIVE;
@@ -137,13 +146,90 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                                                      // been tested once head has passed it (items are consumed in order)
 
     for (;;) {
+        // tails that other lanes of the workgroup have run for this wave's paths: those lanes go on (at their next SHADE phase)
+        if (__ballot((flags & F_WAIT) != 0) != 0ull) {
+            const unsigned long long seen = tail_done[wv];                 // one word, the same for every lane
+            const unsigned long long dn = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(seen >> 32)) << 32) |
+                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seen);
+            if (dn != 0ull) {
+                if (lane == 0) atomicAnd(&tail_done[wv], ~dn);             // only the bits seen: a worker may be adding others right now
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if ((dn >> lane) & 1ull) flags = (flags & ~F_WAIT) | F_RESUME;
+            }
+        }
         const bool trav = (flags & F_TRAV) != 0;
         if (PRUNE && trav && (uint32_t)(keys[lane] >> 32) == 0u) i = 0xFFFFFFFFu;   // settled by a conclusive blocker (distance bits 0): nothing left to walk
         const bool walking = trav && i < N;
-        const bool need_shade = (flags & F_ALIVE) && !(trav && (i < N || (int32_t)(head - lastpos) < 0));
+        const bool need_shade = (flags & F_ALIVE) && !(flags & F_WAIT) && !(trav && (i < N || (int32_t)(head - lastpos) < 0));
         const int nW = __popcll(__ballot(walking)), nS = __popcll(__ballot(need_shade));
+        const int nWait = __popcll(__ballot((flags & F_WAIT) != 0));
         const uint32_t len = tail - head;
-        if ((nW | nS) == 0 && len == 0) break;
+        const bool idle = (nW | nS) == 0 && len == 0;
+        if (idle && nWait == 0) break;
+        // TAIL: the workgroup's pending tails (shade_tail: direct light, bounce, end of sample) are run 64 at a time by whichever
+        // wave gets there first -- once a full batch waits, or at once by a wave that has nothing else to do
+        const uint32_t pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_ctl[0]);
+        if (pend >= (uint32_t)PTX_POOL_TAIL_BATCH || (idle && pend != 0u)) {
+            uint32_t got = 0;
+            if (lane == 0) got = atomicCAS(&tail_ctl[1], 0u, 1u) == 0u ? 1u : 0u;
+            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            if (got) {
+                unsigned long long t_ph = 0;
+                if (COUNT) t_ph = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // gather up to 64 requests: lane w looks after wave w's mask; request number q of the batch goes to lane q
+                const unsigned long long req = lane < (uint32_t)PTX_POOL_WAVES ? tail_req[lane] : 0ull;
+                unsigned long long claimed = 0ull;                         // lane w: the bits this batch takes from wave w
+                uint32_t taken = 0;
+                for (int w = 0; w < PTX_POOL_WAVES; w++) {
+                    const unsigned long long mw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(req >> 32), w) << 32) |
+                                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)req, w);
+                    if (mw == 0ull || taken >= 64u) continue;
+                    const uint32_t r = taken + below(mw);
+                    const bool take = ((mw >> lane) & 1ull) && r < 64u;
+                    if (take) tail_tmp[r] = ((uint32_t)w << 6) | lane;
+                    const unsigned long long cm = __ballot(take);
+                    if (lane == (uint32_t)w) claimed = cm;
+                    taken += (uint32_t)__popcll(cm);
+                }
+                if (claimed != 0ull) atomicAnd(&tail_req[lane], ~claimed);
+                const bool act = lane < taken;
+                const uint32_t who = act ? tail_tmp[lane] : 0u;
+                if (lane == 0) atomicSub(&tail_ctl[0], taken);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) atomicExch(&tail_ctl[1], 0u);               // the batch is ours: the next one may be gathered
+                int st = SH_TRACE;
+                if (act) {
+                    const LdsLane R{&lds_all[0][0] + (who >> 6) * (uint32_t)(PW_C_SAMPLES * 64) + (who & 63u)};
+                    V3 to = mk(0.f, 0.f, 0.f), td = R.ld3(PW_LP);          // the attempt's direction travels in the light-point words
+                    PathLds rp{R, to, td, P, prim_t, prim_tri};
+                    LocalCnt cc = {};
+                    st = shade_tail<MEMO>(S, P, rp, (uint32_t)rp.aux(), cc);
+                    if (st == SH_DONE) {
+                        const V3 rgb = path_result(P, rp);
+                        fb[(size_t)rp.frame() * npix + rp.pix()] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+                    }
+                    R.st3(PW_LP, td);                                      // the new ray's direction (its origin: P, or the camera for a new sample)
+                    rp.set_aux(st);
+                }
+                w_pf += (uint32_t)__popcll(__ballot(act && st == SH_DONE));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (claimed != 0ull) atomicOr(&tail_done[lane], claimed);
+                if (COUNT) {
+                    __builtin_amdgcn_s_waitcnt(0);
+                    const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_ph;
+                    if (lane == 0) { cyc[2] += dt; its[2]++; n_tailp++; n_tails += taken; }   // counted with the SHADE phases
+                }
+                continue;
+            }
+        }
+        if (idle) {                                                        // every lane waits for a tail another wave is running
+            unsigned long long t_sp = 0;
+            if (COUNT) t_sp = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_sleep(4);
+            if (COUNT && lane == 0) { n_spin++; cyc_spin += __builtin_amdgcn_s_memtime() - t_sp; }
+            continue;
+        }
         int phase;   // 0 walk, 1 tri, 2 shade
         if (len >= 64u) phase = 1;
         else {
@@ -312,10 +398,24 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
             }
         } else {
             if (COUNT) { d_shade += need_shade ? 1u : 0u; if (lane == 0) d_shade_s += 64u; }
-            bool run_shade = need_shade && (flags & F_TASK);      // a finished ray (or a pending cached primary hit)
+            bool run_shade = need_shade && (flags & F_TASK) && !(flags & F_RESUME);      // a finished ray (or a pending cached primary hit)
             bool want_task = need_shade && !(flags & F_TASK);
             bool start_trav = false;
             PathLds p{L, ro, rd, P, prim_t, prim_tri};
+            // (0) lanes whose tail has been run (TAIL, above): the result code says how the path goes on
+            if (need_shade && (flags & F_RESUME)) {
+                flags &= ~F_RESUME;
+                const int code = p.aux();
+                if (code == SH_DONE) {                                      // the task is finished (the worker wrote its pixel)
+                    flags &= ~(F_TASK | F_TRAV | F_CACHED);
+                    want_task = true;
+                } else {
+                    rd = L.ld3(PW_LP);
+                    if (p.bounce() == 0) ro = P.src;                        // a new sample starts at the camera (path_new_sample)
+                    if (code == SH_CACHED) { flags = (flags | F_CACHED) & ~F_TRAV; run_shade = true; }
+                    else { flags &= ~F_CACHED; start_trav = true; }
+                }
+            }
             // (1) hand out the wave's next tasks (wave-uniform control flow: the cursor `next` stays uniform)
             for (;;) {
                 const unsigned long long m = __ballot(want_task);
@@ -361,61 +461,55 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                 }
                 w_pf += (uint32_t)__popcll(__ballot(black));
             }
-            // (2) consume finished rays / cached primary hits.  A lane may go through several samples in a row (primary ray
-            //     misses or hits an emitter: every sample ends at once); the loop is wave-uniform so the counters stay scalar
+            // (2) consume finished rays / cached primary hits: shade_front draws the next light attempt or hands the path to a tail
             {
                 float t = 0.f;
                 bool hit = false;
                 int tri = -1;
-                bool cached = (flags & F_CACHED) != 0;
-                if (run_shade && !cached) {
-                    const unsigned long long key = keys[lane];
-                    t = __uint_as_float((uint32_t)(key >> 32));
-                    hit = t < 1.0e38f;
-                    if (hit) {
-                        const uint32_t slot = (uint32_t)key >> 1;
-                        if (p.stage() != ST_PATH && ((uint32_t)key & 1u) == 0u) {
-                            // a light-visibility ray stopped by a triangle without emission: shade_step needs no index (tri < 0);
-                            // the blocker's leaf is remembered for the next attempt instead
-                            tri = -1;
-                            c_noff = S.ref_base + ((uint32_t)__float_as_int(ld16(S.tris, slot * 48u + 32u).w) << 5);
-                        } else {
-                            tri = __float_as_int(ld16(S.tris, slot * 48u).w);
+                if (run_shade) {
+                    if (flags & F_CACHED) {
+                        t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri();
+                    } else {
+                        const unsigned long long key = keys[lane];
+                        t = __uint_as_float((uint32_t)(key >> 32));
+                        hit = t < 1.0e38f;
+                        if (hit) {
+                            const uint32_t slot = (uint32_t)key >> 1;
+                            if (p.stage() != ST_PATH && ((uint32_t)key & 1u) == 0u) {
+                                // a light-visibility ray stopped by a triangle without emission: shade_front needs no index (tri < 0);
+                                // the blocker's leaf is remembered for the next attempt instead
+                                tri = -1;
+                                c_noff = S.ref_base + ((uint32_t)__float_as_int(ld16(S.tris, slot * 48u + 32u).w) << 5);
+                            } else {
+                                tri = __float_as_int(ld16(S.tris, slot * 48u).w);
+                            }
                         }
                     }
                 }
-                bool act = run_shade;
+                LocalCnt cc = {};
+                uint32_t tf = 0;
                 int st = SH_TRACE;
-                // PTX_POOL_DEFER_CACHED: a lane whose sample ended meets its cached primary hit in the NEXT shade phase, together
-                // with the other lanes that have a hit to process, instead of a second pass through shade_step for a few lanes now
-                for (int pass = 0; (PTX_POOL_DEFER_CACHED ? pass == 0 : true) && __ballot(act) != 0ull; pass++) {
-                    LocalCnt cc = {};
-                    if (act) {
-                        if (cached) { t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri(); }
-                        st = shade_step<MEMO>(S, P, p, hit, t, tri, cc);
-                        cached = (st == SH_CACHED);
-                        act = cached;
-                    }
-                    // per call: rays 1 or 2 (the memoised shadow ray), hits 0..2, light attempts 0 or 1
-                    w_rays += (uint32_t)__popcll(__ballot(cc.rays >= 1u)) + (uint32_t)__popcll(__ballot(cc.rays >= 2u));
-                    w_hits += (uint32_t)__popcll(__ballot(cc.ray_hits >= 1u)) + (uint32_t)__popcll(__ballot(cc.ray_hits >= 2u));
-                    w_att += (uint32_t)__popcll(__ballot(cc.light_attempts >= 1u));
-                }
-                bool done = false;
-                if (run_shade && st == SH_CACHED) {            // (deferred) needs shade again: no ray in flight
-                    flags = (flags | F_CACHED) & ~F_TRAV;
-                } else if (run_shade) {
+                if (run_shade) st = shade_front<MEMO>(S, P, p, hit, t, tri, cc, tf);
+                // per call: rays 1 or 2 (the memoised shadow ray), hits 0..2, light attempts 0 or 1
+                w_rays += (uint32_t)__popcll(__ballot(cc.rays >= 1u)) + (uint32_t)__popcll(__ballot(cc.rays >= 2u));
+                w_hits += (uint32_t)__popcll(__ballot(cc.ray_hits >= 1u)) + (uint32_t)__popcll(__ballot(cc.ray_hits >= 2u));
+                w_att += (uint32_t)__popcll(__ballot(cc.light_attempts >= 1u));
+                const bool to_tail = run_shade && st == SH_TAIL;
+                if (run_shade) {
                     flags &= ~F_CACHED;
-                    if (st == SH_DONE) {
-                        const V3 rgb = path_result(P, p);
-                        fb[(size_t)p.frame() * npix + p.pix()] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
-                        done = true;
-                        flags &= ~(F_TASK | F_TRAV);          // takes its next task in the next SHADE phase
+                    if (to_tail) {
+                        L.st3(PW_LP, rd);                                  // the attempt's direction (the light point itself is no longer needed)
+                        p.set_aux((int)tf);
+                        flags = (flags | F_WAIT) & ~F_TRAV;
                     } else {
                         start_trav = true;
                     }
                 }
-                w_pf += (uint32_t)__popcll(__ballot(done));
+                const unsigned long long mt = __ballot(to_tail);
+                if (mt != 0ull) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the path state is in LDS before the request is
+                    if (lane == 0) { atomicOr(&tail_req[wv], mt); atomicAdd(&tail_ctl[0], (uint32_t)__popcll(mt)); }
+                }
             }
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
@@ -453,6 +547,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
     }
     if (COUNT && lane == 0) {
         for (int e = 0; e < 3; e++) { atomicAdd(&counters[CNT_CYC_WALK + e], cyc[e]); atomicAdd(&counters[CNT_IT_WALK + e], its[e]); }
+        atomicAdd(&counters[CNT_TAIL_PASSES], n_tailp); atomicAdd(&counters[CNT_TAILS], n_tails); atomicAdd(&counters[CNT_SPINS], n_spin); atomicAdd(&counters[CNT_CYC_SPIN], cyc_spin);
     }
     LocalCnt c = {};
     if (lane == 0) {   // every task runs exactly spp samples (glsl:521-525), so samples = pixel-frames x spp
