@@ -1542,7 +1542,8 @@ static hipError_t launch_render_pool(ptx_ctx* ctx, const RenderBufs& rb, uint32_
 // the path-tracing kernel of the selected pipeline / traversal / memo / count options over one batch
 static hipError_t launch_path_tracer(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const int sel = prune_mode(ctx) * 4 + (ctx->opt_memo ? 2 : 0) + (ctx->opt_count ? 1 : 0);
-    const int pipeline = (ctx->opt_pipeline == 2 && !ctx->pool_ok) ? 1 : ctx->opt_pipeline;
+    // pipeline 2 needs disjoint leaf ranges, and its packed path state holds L < 2^20 lights and sample_count < 4096 (ptx_pool.h PathLdsC)
+    const int pipeline = (ctx->opt_pipeline == 2 && (!ctx->pool_ok || ctx->S.L >= (1 << 20) || ctx->P.spp >= 4096)) ? 1 : ctx->opt_pipeline;
 #define PTX_SEL(fn)                                                   \
     switch (sel) {                                                    \
         case 0: return fn<0, false, false>(ctx, rb, nf);              \

@@ -63,6 +63,14 @@
 #ifndef PTX_POOL_HOTK
 #define PTX_POOL_HOTK 64          // hot node records per octant layout staged in LDS (8 layouts x 32 B each = 16 KB)
 #endif
+#ifndef PTX_POOL_COLD_MIN
+#define PTX_POOL_COLD_MIN 0       // > 0: walking lanes at a record that is not staged in LDS wait until this many have gathered, and WALK steps in between move only
+                                  // the lanes at staged records (LDS latency only).  Measured on the headline: 0 / 8 / 16 / 32 -> 69.9 / 77.7 / 88.1 / 138.5 ms per frame:
+                                  // the parked lanes cost far more than the shorter steps win.  0 = every step serves every walking lane
+#endif
+#ifndef PTX_POOL_TAIL_POLL
+#define PTX_POOL_TAIL_POLL 4      // power of two
+#endif
 #ifndef PTX_POOL_TAIL_BATCH
 #define PTX_POOL_TAIL_BATCH 64    // pending tails of the workgroup at which a wave stops for a TAIL pass
 #endif
@@ -71,6 +79,55 @@
 #endif
 
 namespace ptx {
+
+// Path state of pipeline 2 in LDS, 24 words per lane (struct-of-arrays like PathLds, ptx_wave.h, but packed tighter: 16 waves
+// x 24 words x 64 lanes = 96 KB of the CU's 160 KB): the sample counter shares a word with the light index, the "light was
+// visible" flag lives in the pack word.  Limits (launch_path_tracer falls back to pipeline 1 beyond them): L < 2^20 lights,
+// sample_count < 4096.
+enum { PC_SX = 0, PC_SY, PC_SUM, PC_THR = PC_SUM + 3, PC_RAD = PC_THR + 3, PC_N = PC_RAD + 3, PC_COL = PC_N + 3, PC_LP = PC_COL + 3,
+       PC_LIS = PC_LP + 3 /* light index | samples finished << 20 */, PC_PACK /* attempts 0..3 | aux 4..7 | stage 8..9 | lvis 10 | bounce 16..31 */,
+       PC_PIX /* pixel | frame-in-batch << 26 */, PC_DIST, PC_WORDS };
+struct PathLdsC {
+    LdsLane L;
+    V3& ro; V3& rd;                       // the ray lives in registers (the traversal needs it every step)
+    const DParams& P;
+    const float* prim_t_; const int* prim_tri_;
+#define X3(f, W) __device__ __forceinline__ V3 f() const { return L.ld3(W); } __device__ __forceinline__ void set_##f(V3 v) const { L.st3(W, v); }
+#define XF(f, W) __device__ __forceinline__ float f() const { return L.ld(W); } __device__ __forceinline__ void set_##f(float v) const { L.st(W, v); }
+#define XU(f, W) __device__ __forceinline__ uint32_t f() const { return (uint32_t)L.ldi(W); } __device__ __forceinline__ void set_##f(uint32_t v) const { L.sti(W, (int)v); }
+    XU(sx, PC_SX) XU(sy, PC_SY) X3(sum, PC_SUM) X3(thr, PC_THR) X3(rad, PC_RAD) X3(n, PC_N) X3(col, PC_COL) X3(lp, PC_LP) XF(dist, PC_DIST)
+#undef X3
+#undef XF
+#undef XU
+    __device__ __forceinline__ int bits(int w, int sh, int mask) const { return (L.ldi(w) >> sh) & mask; }
+    __device__ __forceinline__ void set_bits(int w, int sh, int mask, int v) const { L.sti(w, (L.ldi(w) & ~(mask << sh)) | ((v & mask) << sh)); }
+    __device__ __forceinline__ int li() const { return bits(PC_LIS, 0, 0xFFFFF); }
+    __device__ __forceinline__ void set_li(int v) const { set_bits(PC_LIS, 0, 0xFFFFF, v); }
+    __device__ __forceinline__ int s() const { return (int)((uint32_t)L.ldi(PC_LIS) >> 20); }
+    __device__ __forceinline__ void set_s(int v) const { L.sti(PC_LIS, (L.ldi(PC_LIS) & 0xFFFFF) | (v << 20)); }
+    __device__ __forceinline__ int attempts() const { return bits(PC_PACK, 0, 0xF); }
+    __device__ __forceinline__ void set_attempts(int v) const { set_bits(PC_PACK, 0, 0xF, v); }
+    __device__ __forceinline__ int aux() const { return bits(PC_PACK, 4, 0xF); }          // tail flags on the way to a TAIL pass, its result code on the way back
+    __device__ __forceinline__ void set_aux(int v) const { set_bits(PC_PACK, 4, 0xF, v); }
+    __device__ __forceinline__ int stage() const { return bits(PC_PACK, 8, 0x3); }
+    __device__ __forceinline__ void set_stage(int v) const { set_bits(PC_PACK, 8, 0x3, v); }
+    __device__ __forceinline__ int lvis() const { return bits(PC_PACK, 10, 0x1); }
+    __device__ __forceinline__ void set_lvis(int v) const { set_bits(PC_PACK, 10, 0x1, v); }
+    __device__ __forceinline__ int bounce() const { return (int)((uint32_t)L.ldi(PC_PACK) >> 16); }
+    __device__ __forceinline__ void set_bounce(int v) const { L.sti(PC_PACK, (L.ldi(PC_PACK) & 0xFFFF) | (v << 16)); }
+    __device__ __forceinline__ V3 o() const { return ro; }
+    __device__ __forceinline__ void set_o(V3 v) const { ro = v; }
+    __device__ __forceinline__ V3 d() const { return rd; }
+    __device__ __forceinline__ void set_d(V3 v) const { rd = v; }
+    __device__ __forceinline__ uint32_t pix() const { return (uint32_t)L.ldi(PC_PIX) & 0x03FFFFFFu; }
+    __device__ __forceinline__ uint32_t frame() const { return (uint32_t)L.ldi(PC_PIX) >> 26; }
+    __device__ __forceinline__ V3 dprim() const { const uint32_t px = pix(); return primary_dir(P, px % P.W, px / P.W); }
+    __device__ __forceinline__ void set_dprim(V3) const {}
+    __device__ __forceinline__ float prim_t() const { return prim_t_[pix()]; }
+    __device__ __forceinline__ void set_prim_t(float) const {}
+    __device__ __forceinline__ int prim_tri() const { return prim_tri_[pix()]; }
+    __device__ __forceinline__ void set_prim_tri(int) const {}
+};
 
 #ifdef PTX_HEAT
 __device__ unsigned int g_heat[1u << 20];    // diagnostic build only: node-visit histogram over all layouts
@@ -84,13 +141,13 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                                                     float4* __restrict__ fb, uint32_t n_frames, uint32_t chunk,
                                                     uint32_t* __restrict__ task_counter, unsigned long long* counters) {
     // per wave (private; `wv` selects the wave's slice):
-    __shared__ float lds_all[PTX_POOL_WAVES][PW_C_SAMPLES * 64];         // path state only (25 words per lane); work counters live in scalar registers
+    __shared__ float lds_all[PTX_POOL_WAVES][PC_WORDS * 64];             // path state only (PathLdsC, 24 words per lane); work counters live in scalar registers
     __shared__ unsigned long long keys_all[PTX_POOL_WAVES][64];          // best (t, slot) of the lane's ray
     __shared__ uint2 queue_all[PTX_POOL_WAVES][PTX_POOL_QCAP];
     __shared__ uint32_t kap_all[PRUNE == 1 ? PTX_POOL_WAVES : 1][64];    // PRUNE = 1: packed kappa pair of the lane's ray (ray_kappa), read by whoever tests its leaves
     __shared__ float tlm_all[PTX_POOL_WAVES][64];                        // PRUNE != 0: light_bound of the lane's ray if it is a light-visibility ray, else -3e38
     // shared by the workgroup, read-only after the barrier: the hot_k hottest node records of each octant layout
-    __shared__ float4 hot[PRUNE == 1 ? 2 : 8 * PTX_POOL_HOTK * 2];
+    __shared__ float4 hot[(PRUNE == 1 || PTX_POOL_HOTK == 0) ? 2 : 8 * PTX_POOL_HOTK * 2];
     // TAIL requests of the workgroup: bit l of tail_req[w] = the path of lane l of wave w waits for shade_tail (its state is in
     // that wave's LDS slice); bit l of tail_done[w] = it has been run.  tail_ctl = {requests pending, gather lock}
     __shared__ unsigned long long tail_req[PTX_POOL_WAVES], tail_done[PTX_POOL_WAVES];
@@ -142,12 +199,16 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
     uint32_t probed = 0xFFFFFFFFu;                   // fc word of the leaf the cache has already queued for the running ray: the walk skips it
     uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
     uint32_t hot_off = 0, hot_lim = 0;               // hot_k > 0: LDS byte offset of the ray's octant layout; records below hot_lim are read from LDS
+    uint32_t iter = 0;                               // wave-uniform loop counter (mailbox polling)
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
 
     for (;;) {
-        // tails that other lanes of the workgroup have run for this wave's paths: those lanes go on (at their next SHADE phase)
-        if (__ballot((flags & F_WAIT) != 0) != 0ull) {
+        // tails that other lanes of the workgroup have run for this wave's paths: those lanes go on (at their next SHADE phase).
+        // The mailbox is looked at every PTX_POOL_TAIL_POLL-th iteration (and whenever the wave has nothing else to do): the loop
+        // runs some 18 000 times per frame and wave, and every instruction at its top is paid that often
+        const bool poll = (iter++ & (uint32_t)(PTX_POOL_TAIL_POLL - 1)) == 0u;
+        if (poll && __ballot((flags & F_WAIT) != 0) != 0ull) {
             const unsigned long long seen = tail_done[wv];                 // one word, the same for every lane
             const unsigned long long dn = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(seen >> 32)) << 32) |
                                           (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seen);
@@ -162,13 +223,13 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
         const bool walking = trav && i < N;
         const bool need_shade = (flags & F_ALIVE) && !(flags & F_WAIT) && !(trav && (i < N || (int32_t)(head - lastpos) < 0));
         const int nW = __popcll(__ballot(walking)), nS = __popcll(__ballot(need_shade));
-        const int nWait = __popcll(__ballot((flags & F_WAIT) != 0));
         const uint32_t len = tail - head;
         const bool idle = (nW | nS) == 0 && len == 0;
-        if (idle && nWait == 0) break;
+        if (idle && __ballot((flags & F_WAIT) != 0) == 0ull) break;
         // TAIL: the workgroup's pending tails (shade_tail: direct light, bounce, end of sample) are run 64 at a time by whichever
         // wave gets there first -- once a full batch waits, or at once by a wave that has nothing else to do
-        const uint32_t pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_ctl[0]);
+        uint32_t pend = 0;
+        if (poll || idle) pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_ctl[0]);
         if (pend >= (uint32_t)PTX_POOL_TAIL_BATCH || (idle && pend != 0u)) {
             uint32_t got = 0;
             if (lane == 0) got = atomicCAS(&tail_ctl[1], 0u, 1u) == 0u ? 1u : 0u;
@@ -200,16 +261,16 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                 if (lane == 0) atomicExch(&tail_ctl[1], 0u);               // the batch is ours: the next one may be gathered
                 int st = SH_TRACE;
                 if (act) {
-                    const LdsLane R{&lds_all[0][0] + (who >> 6) * (uint32_t)(PW_C_SAMPLES * 64) + (who & 63u)};
-                    V3 to = mk(0.f, 0.f, 0.f), td = R.ld3(PW_LP);          // the attempt's direction travels in the light-point words
-                    PathLds rp{R, to, td, P, prim_t, prim_tri};
+                    const LdsLane R{&lds_all[0][0] + (who >> 6) * (uint32_t)(PC_WORDS * 64) + (who & 63u)};
+                    V3 to = mk(0.f, 0.f, 0.f), td = R.ld3(PC_LP);          // the attempt's direction travels in the light-point words
+                    PathLdsC rp{R, to, td, P, prim_t, prim_tri};
                     LocalCnt cc = {};
                     st = shade_tail<MEMO>(S, P, rp, (uint32_t)rp.aux(), cc);
                     if (st == SH_DONE) {
                         const V3 rgb = path_result(P, rp);
                         fb[(size_t)rp.frame() * npix + rp.pix()] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
                     }
-                    R.st3(PW_LP, td);                                      // the new ray's direction (its origin: P, or the camera for a new sample)
+                    R.st3(PC_LP, td);                                      // the new ray's direction (its origin: P, or the camera for a new sample)
                     rp.set_aux(st);
                 }
                 w_pf += (uint32_t)__popcll(__ballot(act && st == SH_DONE));
@@ -228,6 +289,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
             if (COUNT) t_sp = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_sleep(4);
             if (COUNT && lane == 0) { n_spin++; cyc_spin += __builtin_amdgcn_s_memtime() - t_sp; }
+            iter = 0;                                                      // look again at once
             continue;
         }
         int phase;   // 0 walk, 1 tri, 2 shade
@@ -287,9 +349,23 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                     bool push = false;
                     uint32_t item = 0;
                     float tn = 0.f;
-                    if (w) {
+                    // Hot records come from LDS (short latency), the others from memory.  A step that issues both kinds of
+                    // load waits for the slower one, so the two are kept apart: a HOT step moves only the lanes whose record is
+                    // staged; lanes at a cold record wait until PTX_POOL_COLD_MIN of them have gathered (or no hot lane is left),
+                    // then one step serves everybody.
+                    bool act = w, cold_step = true;
+                    if (HOT && PTX_POOL_COLD_MIN > 0) {
+                        const bool hl = w && i < hot_lim;
+                        const unsigned long long mh = __ballot(hl);
+                        cold_step = mh == 0ull || __popcll(__ballot(w && !hl)) >= PTX_POOL_COLD_MIN;
+                        act = cold_step ? w : hl;
+                    }
+                    if (act) {
                         float4 a, b;
-                        if (HOT && i < hot_lim) {
+                        if (HOT && !cold_step) {
+                            const float4* h = (const float4*)((const char*)hot + hot_off + (i << 5));
+                            a = h[0]; b = h[1];
+                        } else if (HOT && i < hot_lim) {
                             const float4* h = (const float4*)((const char*)hot + hot_off + (i << 5));
                             a = h[0]; b = h[1];
                         } else {
@@ -326,7 +402,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                         lastpos = pos + 1u;
                     }
                     tail += (uint32_t)__popcll(m);
-                    if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
+                    if (COUNT) { d_walk += act ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
                     w = trav && i < N;
                     if (__popcll(__ballot(w)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
                 }
@@ -401,7 +477,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
             bool run_shade = need_shade && (flags & F_TASK) && !(flags & F_RESUME);      // a finished ray (or a pending cached primary hit)
             bool want_task = need_shade && !(flags & F_TASK);
             bool start_trav = false;
-            PathLds p{L, ro, rd, P, prim_t, prim_tri};
+            PathLdsC p{L, ro, rd, P, prim_t, prim_tri};
             // (0) lanes whose tail has been run (TAIL, above): the result code says how the path goes on
             if (need_shade && (flags & F_RESUME)) {
                 flags &= ~F_RESUME;
@@ -410,7 +486,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                     flags &= ~(F_TASK | F_TRAV | F_CACHED);
                     want_task = true;
                 } else {
-                    rd = L.ld3(PW_LP);
+                    rd = L.ld3(PC_LP);
                     if (p.bounce() == 0) ro = P.src;                        // a new sample starts at the camera (path_new_sample)
                     if (code == SH_CACHED) { flags = (flags | F_CACHED) & ~F_TRAV; run_shade = true; }
                     else { flags &= ~F_CACHED; start_trav = true; }
@@ -444,7 +520,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                         uint32_t px, py;
                         if (tile_pixel(P, tile, mine & 63u, px, py)) {     // else: padding lane of an edge tile, draw again
                             const uint32_t pix = py * P.W + px;
-                            L.sti(PW_PIX, (int)(pix | (frame << 26))); L.sti(PW_PACK, 0);
+                            L.sti(PC_PIX, (int)(pix | (frame << 26))); L.sti(PC_PACK, 0); L.sti(PC_LIS, 0);
                             LocalCnt cb = {};
                             const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], 0.f, 0, cb);
                             if (st == SH_DONE) {                            // max_path_length <= 0: black; draw again
@@ -498,7 +574,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                 if (run_shade) {
                     flags &= ~F_CACHED;
                     if (to_tail) {
-                        L.st3(PW_LP, rd);                                  // the attempt's direction (the light point itself is no longer needed)
+                        L.st3(PC_LP, rd);                                  // the attempt's direction (the light point itself is no longer needed)
                         p.set_aux((int)tf);
                         flags = (flags | F_WAIT) & ~F_TRAV;
                     } else {

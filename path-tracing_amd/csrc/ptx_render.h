@@ -27,7 +27,7 @@ enum { SH_TRACE = 0, SH_CACHED = 1, SH_DONE = 2 };   // what shade_step() wants 
     X3(sum)                  /* sum of the samples' radiance (glsl:524)          */                               \
     X3(dprim) XF(prim_t) XI(prim_tri)   /* primary ray + its cached hit          */                               \
     XI(s)                    /* samples finished                                 */                               \
-    X3(o) X3(d) X3(thr) X3(rad) X3(n) X3(col) X3(lp) XF(lpdf) XF(dist) XI(li) XI(attempts) XI(bounce) XI(stage)
+    X3(o) X3(d) X3(thr) X3(rad) X3(n) X3(col) X3(lp) XI(lvis) XF(dist) XI(li) XI(attempts) XI(bounce) XI(stage)
 
 struct PathRegs {
 #define X3(f) V3 f##_; __device__ __forceinline__ V3 f() const { return f##_; } __device__ __forceinline__ void set_##f(V3 v) { f##_ = v; }
@@ -68,7 +68,7 @@ __device__ __forceinline__ int path_begin(const DParams& P, PT& p, uint32_t px, 
     p.set_prim_t(prim_t); p.set_prim_tri(prim_tri);
     p.set_s(0);
     p.set_n(mk(0.f, 0.f, 0.f)); p.set_col(mk(0.f, 0.f, 0.f)); p.set_lp(mk(0.f, 0.f, 0.f));
-    p.set_lpdf(1.0f); p.set_dist(0.0f); p.set_li(0); p.set_attempts(0);
+    p.set_lvis(0); p.set_dist(0.0f); p.set_li(0); p.set_attempts(0);
     path_new_sample(P, p);
     if (P.max_len <= 0) { c.samples += (uint32_t)P.spp; return SH_DONE; }
     c.samples++;
@@ -124,7 +124,7 @@ __device__ __forceinline__ int shade_front(const DScene& S, const DParams& P, PT
         if (hit) { c.ray_hits++; if (tri >= 0) bem = mk(S.attrE[tri]); }   // tri < 0: a triangle known to have emission (0,0,0) (pipeline 2)
         const bool visible = !(hit && any_ne(bem, lem));                  // glsl:353-363
         if (visible || p.attempts() >= 10) {
-            p.set_lpdf(visible ? S.light[p.li() * 6 + 5].x : 1.0f);            // glsl:389-395
+            p.set_lvis(visible ? 1 : 0);                                     // glsl:389-395: pdf = visible ? 1 / (L * area) : 1 (taken in the tail)
             const V3 nL = mk(S.light[p.li() * 6 + 3]);
             // glsl:431: normalize(lightPoint - P) == the attempt's direction d (same expression)
             if (dot(p.n(), p.d()) > 0.0f && dot(nL, -p.d()) > 0.0f) {           // glsl:435
@@ -175,13 +175,14 @@ __device__ __forceinline__ int shade_tail(const DScene& S, const DParams& P, PT&
         const V3 nL = mk(S.light[p.li() * 6 + 3]);
         const V3 lem = mk(S.light[p.li() * 6 + 4]);
         const float dist = p.dist();
+        const float lpdf = p.lvis() ? S.light[p.li() * 6 + 5].x : 1.0f;      // glsl:389-395
         const float sa = fmaxf(dot(nL, -p.d()), 0.0f) / (dist * dist);
         const V3 brdf = (p.col() * PTX_M_1_PI) * dot(p.n(), p.d());
         const V3 direct = (lem * sa) * brdf;
-        const float bpdf = p.lpdf() * sa;
-        const float f1 = p.lpdf() * p.lpdf(), f2 = bpdf * bpdf;
+        const float bpdf = lpdf * sa;
+        const float f1 = lpdf * lpdf, f2 = bpdf * bpdf;
         const float w = f1 / (f1 + f2);
-        p.set_rad(p.rad() + ((p.thr() * w) * direct) / p.lpdf());
+        p.set_rad(p.rad() + ((p.thr() * w) * direct) / lpdf);
     }
     if (tf & TF_BOUNCE) {                                                 // glsl:459-486
         float r0, r1;

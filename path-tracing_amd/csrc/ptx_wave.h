@@ -80,7 +80,7 @@ struct PathLds {
 #define XI(f, W) __device__ __forceinline__ int f() const { return L.ldi(W); } __device__ __forceinline__ void set_##f(int v) const { L.sti(W, v); }
 #define XU(f, W) __device__ __forceinline__ uint32_t f() const { return (uint32_t)L.ldi(W); } __device__ __forceinline__ void set_##f(uint32_t v) const { L.sti(W, (int)v); }
     XU(sx, PW_SX) XU(sy, PW_SY) X3(sum, PW_SUM) XI(s, PW_S) X3(thr, PW_THR) X3(rad, PW_RAD) X3(n, PW_N) X3(col, PW_COL) X3(lp, PW_LP)
-    XF(lpdf, PW_LPDF) XF(dist, PW_DIST) XI(li, PW_LI)
+    XI(lvis, PW_LPDF) XF(dist, PW_DIST) XI(li, PW_LI)
 #undef X3
 #undef XF
 #undef XI
