@@ -90,8 +90,6 @@ typedef struct ptx_counters {
     uint64_t diag[12];       /* SIMT-efficiency diagnostics, only with option "count" = 1: lane-iterations that did work and
                                 64 x wave-iterations for {node walk, triangle tests, traversal calls}: useful, slots pairs; then shader
                                 cycles and wave-iterations per phase {walk, tri, shade} of pipelines 1 and 2 */
-    uint64_t diag2[4];       /* pipeline 2, only with option "count" = 1: TAIL passes, tails run in them, loop iterations a wave
-                                spent waiting for tails that other waves were running, shader cycles of those iterations */
 } ptx_counters;
 
 /* ---- lifecycle (no reference counterpart: canvas.getContext('webgl2'), main.js:123) ---- */

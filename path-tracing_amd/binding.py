@@ -47,12 +47,11 @@ class CParams(C.Structure):
 
 class CCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "rays_traced", "node_visits", "tri_tests", "ray_hits",
-                                          "light_attempts", "pixel_frames", "kernel_launches")] + [("kernel_ms", C.c_double), ("diag", C.c_uint64 * 12), ("diag2", C.c_uint64 * 4)]
+                                          "light_attempts", "pixel_frames", "kernel_launches")] + [("kernel_ms", C.c_double), ("diag", C.c_uint64 * 12)]
 
     def as_dict(self):
-        d = {n: (float(getattr(self, n)) if n == "kernel_ms" else int(getattr(self, n))) for n, _ in self._fields_ if n not in ("diag", "diag2")}
+        d = {n: (float(getattr(self, n)) if n == "kernel_ms" else int(getattr(self, n))) for n, _ in self._fields_ if n != "diag"}
         d["diag"] = [int(x) for x in self.diag]
-        d["diag2"] = [int(x) for x in self.diag2]
         return d
 
 

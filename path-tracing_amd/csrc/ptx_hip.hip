@@ -338,14 +338,12 @@ struct ptx_ctx {
     int next_slot = 0;
     int opt_anyhit = 1;                         // option "anyhit": light-visibility rays stop at the first conclusive blocker (pipeline 2, pruning on)
     int opt_overlap = 1;                        // option "overlap": 0 = every call on slot 0 (strictly one launch after the other)
-    int opt_hot = PTX_POOL_HOTK;                // option "hot_nodes": records per octant layout that pipeline 2 stages in LDS (0 = none, walk the pre-order layouts)
     std::string err;
 
     // scene
     bool have_scene = false;
     DScene S = {};
     const float4* nodes_sah = nullptr;   // leaf-SAH tree over the reference leaves: 8 direction-octant layouts + the reference tree, or nullptr
-    const float4* nodes_hot = nullptr;   // the same nine layouts with their records hottest first and explicit links (pipeline 2, hot nodes in LDS)
     int N_sah = 0;
     std::vector<void*> scene_allocs;
     float bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0};   // of all triangles (ptx_selfcheck_pruning aims rays with it)
@@ -417,16 +415,9 @@ static hipError_t scratch_for_device(int device, unsigned char** out) {   // `de
 // traversal option: bit 0 = best-t pruning, bit 1 = walk the leaf-SAH tree instead of the reference tree
 static inline int prune_mode(const ptx_ctx* c) { return ((c->opt_traversal & 1) && c->prune_ok) ? c->opt_prune : 0; }   // the kernels' PRUNE parameter
 static inline float __uint_as_float_host(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
-static inline DScene scene_view(const ptx_ctx* c, bool for_pool = false) {
+static inline DScene scene_view(const ptx_ctx* c) {
     DScene S = c->S;
     if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; S.oct_stride = (uint32_t)c->N_sah * 32u; S.ref_base = 8u * S.oct_stride; }
-    // pipeline 2 walks the hot-first copies (explicit links; the first hot_k records of each octant layout are staged in LDS).
-    // Not under the provable rule: its inner nodes carry their pruning coefficients where the explicit link goes.
-    S.hot_k = 0;
-    if (for_pool && c->opt_hot > 0 && (c->opt_traversal & 2) && c->nodes_hot && prune_mode(c) != 1) {
-        S.nodes = c->nodes_hot;
-        S.hot_k = (uint32_t)std::min<int>(c->opt_hot, std::min<int>(c->N_sah, PTX_POOL_HOTK));
-    }
     if (!c->opt_anyhit) S.n_lbox = 0;              // (kernels without pruning never look at the boxes)
     // provable rule: with emitters whose position-error coefficient is this large the bound never lets a ray stop (pixar_room's
     // lamp: c_o = 0.054, slack = c_o * kappa of several scene units), and computing it would only cost time
@@ -773,10 +764,9 @@ static int sah_build(std::vector<SahItem>& items, std::vector<uint32_t>& ids, si
 // about the normal (bounce rays), half towards a point on a light (shadow rays) -- walked front-to-back through the binary
 // tree with the kernels' best-t pruning; q(x) = entered(x) / visited(x), smoothed towards the surface-area ratio where a
 // node saw few rays.  Deterministic (fixed seed); affects only the cost of the walk, never its result.
-struct SampleRay { double o[3], d[3], inv[3]; double best, limit; };
-// the sample rays themselves (deterministic: fixed seed, fixed draw order)
-static std::vector<SampleRay> sah_sample_rays(const ptx_scene* sc) {
-    std::vector<SampleRay> rays;
+static void sah_sample(const ptx_scene* sc, std::vector<SahNode>& tree) {
+    const size_t n = tree.size();
+    std::vector<uint32_t> vis(n, 0), ent(n, 0);
     std::vector<double> cum(sc->T);
     double tot = 0;
     auto tri = [&](uint32_t t, int v, int k) { return (double)sc->coords[9 * (size_t)t + 3 * v + k]; };
@@ -787,12 +777,24 @@ static std::vector<SampleRay> sah_sample_rays(const ptx_scene* sc) {
         tot += 0.5 * std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
         cum[t] = tot;
     }
-    if (!(tot > 0)) return rays;                                   // no area to sample from
+    auto finish = [&]() {
+        for (size_t x = 0; x < n; x++) {
+            double prior = 1.0;                                    // surface-area ratio, worth 8 pseudo-observations
+            if (tree[x].parent >= 0) {
+                const double pa = half_area(tree[tree[x].parent].mn, tree[tree[x].parent].mx);
+                prior = pa > 0 ? std::min(1.0, half_area(tree[x].mn, tree[x].mx) / pa) : 1.0;
+            }
+            tree[x].q = ((double)ent[x] + 8.0 * prior) / ((double)vis[x] + 8.0);
+        }
+    };
+    if (!(tot > 0)) { finish(); return; }                          // no area to sample from: surface-area ratios alone
     uint64_t rng = 0x9E3779B97F4A7C15ull;
     auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
-    rays.reserve(65536);
+    struct Ray { double o[3], d[3], inv[3]; double best, limit; };
+    // recursive walk = the threaded pre-order walk of the octant layout for this ray's direction signs
+    std::vector<int> stack;
     for (int r = 0; r < 65536; r++) {
-        SampleRay ray;
+        Ray ray;
         const uint32_t t = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), rnd() * tot) - cum.begin());
         const uint32_t tt = std::min(t, sc->T - 1);
         double u = rnd(), v = rnd();
@@ -819,47 +821,6 @@ static std::vector<SampleRay> sah_sample_rays(const ptx_scene* sc) {
         if (!(dl > 0)) continue;
         for (int k = 0; k < 3; k++) { ray.d[k] /= dl; ray.inv[k] = 1.0 / ray.d[k]; }
         ray.best = 1e38; ray.limit = 3e38;
-        rays.push_back(ray);
-    }
-    return rays;
-}
-// the triangles of leaf `fc` against a sample ray (double precision; best-t and the default rule's limit are updated)
-static void sah_sample_leaf(const ptx_scene* sc, int fc, SampleRay& ray) {
-    auto tri = [&](uint32_t t, int v, int k) { return (double)sc->coords[9 * (size_t)t + 3 * v + k]; };
-    const uint32_t first = (uint32_t)fc & 0x00FFFFFFu, cnt = ((uint32_t)fc >> 24) & 0x7Fu;
-    for (uint32_t q = 0; q < cnt; q++) {
-        const uint32_t ti = (uint32_t)sc->inorder_tri[first + q];
-        const double e1[3] = {tri(ti, 1, 0) - tri(ti, 0, 0), tri(ti, 1, 1) - tri(ti, 0, 1), tri(ti, 1, 2) - tri(ti, 0, 2)};
-        const double e2[3] = {tri(ti, 2, 0) - tri(ti, 0, 0), tri(ti, 2, 1) - tri(ti, 0, 1), tri(ti, 2, 2) - tri(ti, 0, 2)};
-        const double h[3] = {ray.d[1] * e2[2] - ray.d[2] * e2[1], ray.d[2] * e2[0] - ray.d[0] * e2[2], ray.d[0] * e2[1] - ray.d[1] * e2[0]};
-        const double a = e1[0] * h[0] + e1[1] * h[1] + e1[2] * h[2];
-        if (std::fabs(a) < 1e-4) continue;
-        const double f = 1.0 / a, sx[3] = {ray.o[0] - tri(ti, 0, 0), ray.o[1] - tri(ti, 0, 1), ray.o[2] - tri(ti, 0, 2)};
-        const double uq = f * (sx[0] * h[0] + sx[1] * h[1] + sx[2] * h[2]);
-        if (uq < 0 || uq > 1) continue;
-        const double qv[3] = {sx[1] * e1[2] - sx[2] * e1[1], sx[2] * e1[0] - sx[0] * e1[2], sx[0] * e1[1] - sx[1] * e1[0]};
-        const double vq = f * (ray.d[0] * qv[0] + ray.d[1] * qv[1] + ray.d[2] * qv[2]);
-        if (vq < 0 || uq + vq > 1) continue;
-        const double tq = f * (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]);
-        if (tq > 1e-4 && tq < ray.best) { ray.best = tq; ray.limit = tq * (1.0 + PTX_PRUNE_REL) + PTX_PRUNE_ABS; }
-    }
-}
-static void sah_sample(const ptx_scene* sc, std::vector<SahNode>& tree) {
-    const size_t n = tree.size();
-    std::vector<uint32_t> vis(n, 0), ent(n, 0);
-    auto finish = [&]() {
-        for (size_t x = 0; x < n; x++) {
-            double prior = 1.0;                                    // surface-area ratio, worth 8 pseudo-observations
-            if (tree[x].parent >= 0) {
-                const double pa = half_area(tree[tree[x].parent].mn, tree[tree[x].parent].mx);
-                prior = pa > 0 ? std::min(1.0, half_area(tree[x].mn, tree[x].mx) / pa) : 1.0;
-            }
-            tree[x].q = ((double)ent[x] + 8.0 * prior) / ((double)vis[x] + 8.0);
-        }
-    };
-    // recursive walk = the threaded pre-order walk of the octant layout for this ray's direction signs
-    std::vector<int> stack;
-    for (SampleRay ray : sah_sample_rays(sc)) {
         stack.clear();
         stack.push_back(0);
         while (!stack.empty()) {
@@ -879,65 +840,27 @@ static void sah_sample(const ptx_scene* sc, std::vector<SahNode>& tree) {
                 stack.push_back(neg ? nd.left : nd.right);       // second
                 stack.push_back(neg ? nd.right : nd.left);       // first (popped next)
             } else if (nd.fc >= 0) {
-                sah_sample_leaf(sc, nd.fc, ray);
+                const uint32_t first = (uint32_t)nd.fc & 0x00FFFFFFu, cnt = ((uint32_t)nd.fc >> 24) & 0x7Fu;
+                for (uint32_t q = 0; q < cnt; q++) {
+                    const uint32_t ti = (uint32_t)sc->inorder_tri[first + q];
+                    const double e1[3] = {tri(ti, 1, 0) - tri(ti, 0, 0), tri(ti, 1, 1) - tri(ti, 0, 1), tri(ti, 1, 2) - tri(ti, 0, 2)};
+                    const double e2[3] = {tri(ti, 2, 0) - tri(ti, 0, 0), tri(ti, 2, 1) - tri(ti, 0, 1), tri(ti, 2, 2) - tri(ti, 0, 2)};
+                    const double h[3] = {ray.d[1] * e2[2] - ray.d[2] * e2[1], ray.d[2] * e2[0] - ray.d[0] * e2[2], ray.d[0] * e2[1] - ray.d[1] * e2[0]};
+                    const double a = e1[0] * h[0] + e1[1] * h[1] + e1[2] * h[2];
+                    if (std::fabs(a) < 1e-4) continue;
+                    const double f = 1.0 / a, sx[3] = {ray.o[0] - tri(ti, 0, 0), ray.o[1] - tri(ti, 0, 1), ray.o[2] - tri(ti, 0, 2)};
+                    const double uq = f * (sx[0] * h[0] + sx[1] * h[1] + sx[2] * h[2]);
+                    if (uq < 0 || uq > 1) continue;
+                    const double qv[3] = {sx[1] * e1[2] - sx[2] * e1[1], sx[2] * e1[0] - sx[0] * e1[2], sx[0] * e1[1] - sx[1] * e1[0]};
+                    const double vq = f * (ray.d[0] * qv[0] + ray.d[1] * qv[1] + ray.d[2] * qv[2]);
+                    if (vq < 0 || uq + vq > 1) continue;
+                    const double tq = f * (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]);
+                    if (tq > 1e-4 && tq < ray.best) { ray.best = tq; ray.limit = tq * (1.0 + PTX_PRUNE_REL) + PTX_PRUNE_ABS; }
+                }
             }
         }
     }
     finish();
-}
-
-// Hot-first layouts (pipeline 2, LDS-staged hot nodes; DESIGN.md "Hot nodes in LDS").  `lay` holds the 8 pre-order octant
-// layouts of n2 records each ({near.xyz, miss}, {far.xyz, fc}).  The same sample rays are walked through the layout of their
-// octant -- the threaded walk the kernel makes, default pruning rule -- and the records of each layout are re-ordered by
-// visit count, hottest first (the root stays at 0), with EXPLICIT links, since pre-order adjacency is gone:
-//   miss link -> the new index of the old target; leaf: fc unchanged (after a leaf the walk continues at its miss link, hit or
-//   not: in pre-order the record after a leaf IS its miss target); inner node: fc = 0x80000000 | new index of its first child;
-//   empty leaf: fc = 0x80000000 | new index of its miss target (0x7FFFFFFF = end).
-// So index < K <=> one of the K hottest records of that layout, which is all the kernel needs to know to read it from LDS.
-// Only the order of the records in memory changes: the walk visits the same boxes in the same sequence.
-static void sah_hot_layouts(const ptx_scene* sc, const std::vector<float4>& lay, int n2, std::vector<float4>& hot) {
-    auto ibits = [](float f) { int32_t v; std::memcpy(&v, &f, 4); return v; };
-    auto fbits = [](int32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
-    std::vector<std::vector<uint32_t>> heat(8, std::vector<uint32_t>((size_t)n2, 0));
-    for (SampleRay ray : sah_sample_rays(sc)) {
-        const int oct = (ray.d[0] < 0 ? 1 : 0) | (ray.d[1] < 0 ? 2 : 0) | (ray.d[2] < 0 ? 4 : 0);
-        const float4* L = lay.data() + (size_t)oct * n2 * 2;
-        std::vector<uint32_t>& h = heat[oct];
-        for (int32_t i = 0; i >= 0 && i < n2;) {
-            h[(size_t)i]++;
-            const float4 lo = L[2 * (size_t)i], hi = L[2 * (size_t)i + 1];
-            const float mn[3] = {lo.x, lo.y, lo.z}, mx[3] = {hi.x, hi.y, hi.z};
-            double tn = -1e300, tf = 1e300;
-            for (int k = 0; k < 3; k++) {
-                const double t1 = ((double)mn[k] - ray.o[k]) * ray.inv[k], t2 = ((double)mx[k] - ray.o[k]) * ray.inv[k];
-                tn = std::max(tn, std::min(t1, t2)); tf = std::min(tf, std::max(t1, t2));
-            }
-            if (!(tn <= tf && tf > 0) || tn > ray.limit) { i = ibits(lo.w); continue; }
-            const int32_t fc = ibits(hi.w);
-            if (fc >= 0) sah_sample_leaf(sc, fc, ray);
-            i++;
-        }
-    }
-    hot.assign(lay.size(), make_float4(0.f, 0.f, 0.f, 0.f));
-    std::vector<int32_t> order((size_t)n2), rank((size_t)n2);
-    for (int oct = 0; oct < 8; oct++) {
-        const float4* L = lay.data() + (size_t)oct * n2 * 2;
-        float4* H = hot.data() + (size_t)oct * n2 * 2;
-        const std::vector<uint32_t>& h = heat[oct];
-        for (int32_t p = 0; p < n2; p++) order[(size_t)p] = p;
-        std::stable_sort(order.begin() + 1, order.end(), [&](int32_t a, int32_t b) { return h[(size_t)a] > h[(size_t)b]; });   // root first, ties in pre-order
-        for (int32_t r = 0; r < n2; r++) rank[(size_t)order[(size_t)r]] = r;
-        for (int32_t p = 0; p < n2; p++) {
-            float4 lo = L[2 * (size_t)p], hi = L[2 * (size_t)p + 1];
-            const int32_t miss = ibits(lo.w), fc = ibits(hi.w);
-            const int32_t miss2 = miss < 0 ? -1 : rank[(size_t)miss];
-            const bool inner = miss < 0 ? (p + 1 < n2) : (miss != p + 1);       // a leaf's subtree is itself
-            lo.w = fbits(miss2);
-            if (fc < 0) hi.w = fbits((int32_t)(0x80000000u | (uint32_t)(inner ? rank[(size_t)p + 1] : (miss2 < 0 ? 0x7FFFFFFF : miss2))));
-            H[2 * (size_t)rank[(size_t)p]] = lo;
-            H[2 * (size_t)rank[(size_t)p] + 1] = hi;
-        }
-    }
 }
 
 // Contraction: an inner node whose box is almost always hit when its parent's is costs a test and rejects nothing; leaving
@@ -1000,7 +923,7 @@ static void sah_flatten(const std::vector<SahNode>& tree, SahPlan& pl, int node,
 }
 
 // out: 8 layouts (one per direction octant) of N2 nodes each, same 32-B record format as the reference tree
-static bool build_leaf_sah(const ptx_scene* sc, const std::vector<TriCoef>& leaf_coef, std::vector<float4>& out, int* n2, std::vector<float4>& hot) {
+static bool build_leaf_sah(const ptx_scene* sc, const std::vector<TriCoef>& leaf_coef, std::vector<float4>& out, int* n2) {
     if (!ref_tree_is_monotone(sc)) return false;
     std::vector<SahItem> items;
     for (uint32_t i = 0; i < sc->N; i++) {
@@ -1051,7 +974,6 @@ static bool build_leaf_sah(const ptx_scene* sc, const std::vector<TriCoef>& leaf
         }
     }
     *n2 = N2;
-    sah_hot_layouts(sc, out, N2, hot);
     return true;
 }
 
@@ -1342,11 +1264,11 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     for (int j = 0; j < n_cls; j++) S.cls[j] = cls[j];
     S.n_lbox = n_lbox; S.lcoefs = lcoefs;
     std::memcpy(S.lbox, lbox, sizeof(lbox));
-    ctx->nodes_sah = nullptr; ctx->nodes_hot = nullptr; ctx->N_sah = 0;
+    ctx->nodes_sah = nullptr; ctx->N_sah = 0;
     {
-        std::vector<float4> sah, hot;
+        std::vector<float4> sah;
         int n2 = 0;
-        if (build_leaf_sah(sc, leaf_coef, sah, &n2, hot)) {
+        if (build_leaf_sah(sc, leaf_coef, sah, &n2)) {
             // nine layouts of nmax records each: the eight octant layouts of the leaf-SAH tree, then the reference tree
             // itself, which rays with an infinite 1/d component walk (slab_node_ref).  Shorter layouts end in records that
             // no ray enters (NaN box, miss link -1, nothing to queue), so one node count serves all nine.
@@ -1364,24 +1286,6 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
                 repack_nodes(all);
                 if ((rc = upload(ctx, all, &ctx->nodes_sah))) { free_scene(ctx); return rc; }
                 ctx->N_sah = (int)nmax;
-                // the same nine layouts once more for pipeline 2's LDS-staged hot nodes: records hottest first, explicit links
-                // (sah_hot_layouts); the reference tree keeps its order and gets explicit links too (first child = i + 1)
-                for (size_t q = 0; q < nmax * 8; q++) {
-                    all[2 * q] = make_float4(nan, nan, nan, bits(-1));
-                    all[2 * q + 1] = make_float4(nan, nan, nan, bits((int32_t)0xFFFFFFFFu));      // hit link 0x7FFFFFFF = end (never taken: NaN box)
-                }
-                for (int oct = 0; oct < 8; oct++)
-                    std::copy(hot.begin() + (size_t)oct * n2 * 2, hot.begin() + (size_t)(oct + 1) * n2 * 2, all.begin() + (size_t)oct * nmax * 2);
-                {
-                    std::vector<float4> head(all.begin(), all.begin() + (size_t)8 * nmax * 2);
-                    repack_nodes(head);
-                    std::copy(head.begin(), head.end(), all.begin());
-                }
-                for (size_t q = (size_t)8 * nmax; q < (size_t)9 * nmax; q++) {             // layout 8 is already repacked: {.., .., miss, fc}
-                    int32_t fc; std::memcpy(&fc, &all[2 * q + 1].w, 4);
-                    if (fc < 0) all[2 * q + 1].w = bits((int32_t)(0x80000000u | (uint32_t)(q - (size_t)8 * nmax + 1)));
-                }
-                if ((rc = upload(ctx, all, &ctx->nodes_hot))) { free_scene(ctx); return rc; }
             }
         }
     }
@@ -1448,7 +1352,6 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     else if (k == "prune" && (value == 1 || value == 2)) { ctx->opt_prune = (int)value; ctx->prim_valid = false; }
     else if (k == "overlap" && (value == 0 || value == 1)) ctx->opt_overlap = (int)value;
     else if (k == "anyhit" && (value == 0 || value == 1)) ctx->opt_anyhit = (int)value;
-    else if (k == "hot_nodes" && value >= 0 && value <= PTX_POOL_HOTK) ctx->opt_hot = (int)value;
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;
@@ -1527,14 +1430,14 @@ static hipError_t launch_render_pool(ptx_ctx* ctx, const RenderBufs& rb, uint32_
     uint64_t& resident = ctx->pool_resident[PRUNE * 4 + (MEMO ? 2 : 0) + (COUNT ? 1 : 0)];   // waves one residency of the chip holds
     if (resident == 0) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64 * PTX_POOL_WAVES, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_render_pool<PRUNE, MEMO, COUNT>, 64, 0) != hipSuccess || per_cu < 1) per_cu = 16;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
-        resident = (uint64_t)per_cu * (uint64_t)cus;   // workgroups; any value is correct (waves draw work until none is left); this one fills the chip
+        resident = (uint64_t)per_cu * (uint64_t)cus;   // any value is correct (waves draw work until none is left); this one fills the chip
     }
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident, ((total + chunk - 1) / chunk + PTX_POOL_WAVES - 1) / PTX_POOL_WAVES);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident, (total + chunk - 1) / chunk);
     hipError_t e = hipMemsetAsync(rb.task_counter, 0, sizeof(uint32_t), rb.stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64 * PTX_POOL_WAVES), 0, rb.stream, scene_view(ctx, true), ctx->P, rb.ts, ctx->d_prim_t,
+    hipLaunchKernelGGL((k_render_pool<PRUNE, MEMO, COUNT>), dim3(blocks), dim3(64), 0, rb.stream, scene_view(ctx), ctx->P, rb.ts, ctx->d_prim_t,
                        ctx->d_prim_tri, rb.fb, nf, chunk, rb.task_counter, ctx->d_counters);
     return hipGetLastError();
 }
@@ -1542,8 +1445,7 @@ static hipError_t launch_render_pool(ptx_ctx* ctx, const RenderBufs& rb, uint32_
 // the path-tracing kernel of the selected pipeline / traversal / memo / count options over one batch
 static hipError_t launch_path_tracer(ptx_ctx* ctx, const RenderBufs& rb, uint32_t nf) {
     const int sel = prune_mode(ctx) * 4 + (ctx->opt_memo ? 2 : 0) + (ctx->opt_count ? 1 : 0);
-    // pipeline 2 needs disjoint leaf ranges, and its packed path state holds L < 2^20 lights and sample_count < 4096 (ptx_pool.h PathLdsC)
-    const int pipeline = (ctx->opt_pipeline == 2 && (!ctx->pool_ok || ctx->S.L >= (1 << 20) || ctx->P.spp >= 4096)) ? 1 : ctx->opt_pipeline;
+    const int pipeline = (ctx->opt_pipeline == 2 && !ctx->pool_ok) ? 1 : ctx->opt_pipeline;
 #define PTX_SEL(fn)                                                   \
     switch (sel) {                                                    \
         case 0: return fn<0, false, false>(ctx, rb, nf);              \
@@ -1939,7 +1841,6 @@ extern "C" int ptx_get_counters(ptx_ctx* ctx, ptx_counters* out) {
     out->kernel_launches = ctx->kernel_launches;
     out->kernel_ms = ctx->kernel_ms;
     for (int k = 0; k < 12; k++) out->diag[k] = h[CNT_WALK_USEFUL + k];
-    for (int k = 0; k < 4; k++) out->diag2[k] = h[CNT_TAIL_PASSES + k];
     return PTX_OK;
 }
 
@@ -1985,22 +1886,6 @@ extern "C" int ptx_get_size(const ptx_ctx* ctx, uint32_t* width, uint32_t* heigh
     *width = c->P.W; *height = c->P.H;
     return PTX_OK;
 }
-
-#ifdef PTX_HEAT
-// diagnostic build only (tools/dbg/heat.py): the node-visit histogram of pipeline 2 and the node records it indexes
-extern "C" int ptx_dbg_heat(ptx_ctx* ctx, unsigned int* out, uint32_t n, float* nodes_out, uint32_t* n_nodes, uint32_t* n_per_layout) {
-    if (!ctx || !out) return PTX_ERR_INVALID;
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, sync_all(ctx));
-    HIP_TRY(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(ptx::g_heat), (size_t)std::min<uint32_t>(n, 1u << 20) * 4u));
-    const DScene S = scene_view(ctx);
-    const uint32_t total = S.oct_stride ? 9u * (uint32_t)S.N : (uint32_t)S.N;
-    if (n_nodes) *n_nodes = total;
-    if (n_per_layout) *n_per_layout = (uint32_t)S.N;
-    if (nodes_out) HIP_TRY(ctx, hipMemcpy(nodes_out, S.nodes, (size_t)std::min<uint32_t>(total, n) * 32u, hipMemcpyDeviceToHost));
-    return PTX_OK;
-}
-#endif
 
 // ------------------------------------------------------------------------------------------ multi-GPU
 // Every (pixel, frame) is independent, so G GPUs render frames {g, g + G, ...} of the timestamp list over the full image
@@ -2347,7 +2232,6 @@ static int multi_get_counters(ptx_ctx* m, ptx_counters* out) {
         out->kernel_launches += c.kernel_launches;
         out->kernel_ms = std::max(out->kernel_ms, c.kernel_ms);       // the devices run side by side: the busiest one's time
         for (int k = 0; k < 12; k++) out->diag[k] += c.diag[k];
-        for (int k = 0; k < 4; k++) out->diag2[k] += c.diag2[k];
     }
     return PTX_OK;
 }

@@ -39,9 +39,6 @@ struct DScene {
     uint32_t oct_stride;   // bytes between the 8 direction-octant layouts of `nodes` (0: a single layout)
     uint32_t ref_base;     // byte offset in `nodes` of the reference tree itself (layout 8 behind the octant layouts; 0 when
                            // `nodes` IS the reference tree): rays with an infinite 1/d component walk it (slab_node_ref)
-    uint32_t hot_k;        // pipeline 2 only.  > 0: `nodes` holds the hot-first layouts with EXPLICIT links (inner node: fc =
-                           // 0x80000000 | index of its first child; after a leaf, hit or not, the walk goes to the miss link) and
-                           // the first hot_k records of each octant layout are read from LDS.  0: pre-order layouts, hit -> i + 1
     V3 center;             // centre of the scene's bounding box                         } provable pruning: ray_kappa()
     float two_rs, m_cap;   // twice its half-diagonal; largest M_ray the coefficients hold for }
     int n_cls;             // dominant plane normals of the scene's large flat triangles ("classes", unit vectors)
@@ -61,8 +58,7 @@ struct DParams {
 
 // device-side work counters (u64), one block of these per context
 enum { CNT_SAMPLES = 0, CNT_RAYS, CNT_RAYS_TRACED, CNT_NODE_VISITS, CNT_TRI_TESTS, CNT_RAY_HITS, CNT_LIGHT_ATTEMPTS, CNT_PIXEL_FRAMES,
-       CNT_WALK_USEFUL, CNT_WALK_SLOTS, CNT_TRI_USEFUL, CNT_TRI_SLOTS, CNT_TRACE_USEFUL, CNT_TRACE_SLOTS, CNT_CYC_WALK, CNT_CYC_TRI, CNT_CYC_SHADE, CNT_IT_WALK, CNT_IT_TRI, CNT_IT_SHADE,
-       CNT_TAIL_PASSES, CNT_TAILS, CNT_SPINS, CNT_CYC_SPIN, CNT_NUM };
+       CNT_WALK_USEFUL, CNT_WALK_SLOTS, CNT_TRI_USEFUL, CNT_TRI_SLOTS, CNT_TRACE_USEFUL, CNT_TRACE_SLOTS, CNT_CYC_WALK, CNT_CYC_TRI, CNT_CYC_SHADE, CNT_IT_WALK, CNT_IT_TRI, CNT_IT_SHADE, CNT_NUM };
 
 struct LocalCnt {
     uint32_t samples, rays, rays_traced, node_visits, tri_tests, ray_hits, light_attempts;

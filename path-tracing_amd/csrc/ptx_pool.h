@@ -55,120 +55,25 @@
 #define PTX_POOL_CACHE_RESET 0   // 0: the blocker cache survives bounces and samples (63.6 -> 62.7 ms per headline frame: the next bounce is
                                  // often shadowed by the same object); a separate entry for bounce 0 (same point for every sample): no gain
 #endif
-#ifndef PTX_POOL_WAVES
-#define PTX_POOL_WAVES 16         // waves per workgroup.  One workgroup per CU: its waves share the LDS copy of the hot node records;
-                                  // everything else in LDS (path state, keys, leaf queue) is private to a wave, and after the one
-                                  // barrier behind the copy the waves never synchronise again
-#endif
-#ifndef PTX_POOL_HOTK
-#define PTX_POOL_HOTK 64          // hot node records per octant layout staged in LDS (8 layouts x 32 B each = 16 KB)
-#endif
-#ifndef PTX_POOL_COLD_MIN
-#define PTX_POOL_COLD_MIN 0       // > 0: walking lanes at a record that is not staged in LDS wait until this many have gathered, and WALK steps in between move only
-                                  // the lanes at staged records (LDS latency only).  Measured on the headline: 0 / 8 / 16 / 32 -> 69.9 / 77.7 / 88.1 / 138.5 ms per frame:
-                                  // the parked lanes cost far more than the shorter steps win.  0 = every step serves every walking lane
-#endif
-#ifndef PTX_POOL_TAIL_POLL
-#define PTX_POOL_TAIL_POLL 4      // power of two
-#endif
-#ifndef PTX_POOL_TAIL_BATCH
-#define PTX_POOL_TAIL_BATCH 64    // pending tails of the workgroup at which a wave stops for a TAIL pass
-#endif
 #ifndef PTX_POOL_MIN_WAVES
-#define PTX_POOL_MIN_WAVES (PTX_POOL_WAVES / 4)   // waves per SIMD the register allocation aims for (4 -> 128 VGPRs)
+#define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
 #endif
 
 namespace ptx {
 
-// Path state of pipeline 2 in LDS, 24 words per lane (struct-of-arrays like PathLds, ptx_wave.h, but packed tighter: 16 waves
-// x 24 words x 64 lanes = 96 KB of the CU's 160 KB): the sample counter shares a word with the light index, the "light was
-// visible" flag lives in the pack word.  Limits (launch_path_tracer falls back to pipeline 1 beyond them): L < 2^20 lights,
-// sample_count < 4096.
-enum { PC_SX = 0, PC_SY, PC_SUM, PC_THR = PC_SUM + 3, PC_RAD = PC_THR + 3, PC_N = PC_RAD + 3, PC_COL = PC_N + 3, PC_LP = PC_COL + 3,
-       PC_LIS = PC_LP + 3 /* light index | samples finished << 20 */, PC_PACK /* attempts 0..3 | aux 4..7 | stage 8..9 | lvis 10 | bounce 16..31 */,
-       PC_PIX /* pixel | frame-in-batch << 26 */, PC_DIST, PC_WORDS };
-struct PathLdsC {
-    LdsLane L;
-    V3& ro; V3& rd;                       // the ray lives in registers (the traversal needs it every step)
-    const DParams& P;
-    const float* prim_t_; const int* prim_tri_;
-#define X3(f, W) __device__ __forceinline__ V3 f() const { return L.ld3(W); } __device__ __forceinline__ void set_##f(V3 v) const { L.st3(W, v); }
-#define XF(f, W) __device__ __forceinline__ float f() const { return L.ld(W); } __device__ __forceinline__ void set_##f(float v) const { L.st(W, v); }
-#define XU(f, W) __device__ __forceinline__ uint32_t f() const { return (uint32_t)L.ldi(W); } __device__ __forceinline__ void set_##f(uint32_t v) const { L.sti(W, (int)v); }
-    XU(sx, PC_SX) XU(sy, PC_SY) X3(sum, PC_SUM) X3(thr, PC_THR) X3(rad, PC_RAD) X3(n, PC_N) X3(col, PC_COL) X3(lp, PC_LP) XF(dist, PC_DIST)
-#undef X3
-#undef XF
-#undef XU
-    __device__ __forceinline__ int bits(int w, int sh, int mask) const { return (L.ldi(w) >> sh) & mask; }
-    __device__ __forceinline__ void set_bits(int w, int sh, int mask, int v) const { L.sti(w, (L.ldi(w) & ~(mask << sh)) | ((v & mask) << sh)); }
-    __device__ __forceinline__ int li() const { return bits(PC_LIS, 0, 0xFFFFF); }
-    __device__ __forceinline__ void set_li(int v) const { set_bits(PC_LIS, 0, 0xFFFFF, v); }
-    __device__ __forceinline__ int s() const { return (int)((uint32_t)L.ldi(PC_LIS) >> 20); }
-    __device__ __forceinline__ void set_s(int v) const { L.sti(PC_LIS, (L.ldi(PC_LIS) & 0xFFFFF) | (v << 20)); }
-    __device__ __forceinline__ int attempts() const { return bits(PC_PACK, 0, 0xF); }
-    __device__ __forceinline__ void set_attempts(int v) const { set_bits(PC_PACK, 0, 0xF, v); }
-    __device__ __forceinline__ int aux() const { return bits(PC_PACK, 4, 0xF); }          // tail flags on the way to a TAIL pass, its result code on the way back
-    __device__ __forceinline__ void set_aux(int v) const { set_bits(PC_PACK, 4, 0xF, v); }
-    __device__ __forceinline__ int stage() const { return bits(PC_PACK, 8, 0x3); }
-    __device__ __forceinline__ void set_stage(int v) const { set_bits(PC_PACK, 8, 0x3, v); }
-    __device__ __forceinline__ int lvis() const { return bits(PC_PACK, 10, 0x1); }
-    __device__ __forceinline__ void set_lvis(int v) const { set_bits(PC_PACK, 10, 0x1, v); }
-    __device__ __forceinline__ int bounce() const { return (int)((uint32_t)L.ldi(PC_PACK) >> 16); }
-    __device__ __forceinline__ void set_bounce(int v) const { L.sti(PC_PACK, (L.ldi(PC_PACK) & 0xFFFF) | (v << 16)); }
-    __device__ __forceinline__ V3 o() const { return ro; }
-    __device__ __forceinline__ void set_o(V3 v) const { ro = v; }
-    __device__ __forceinline__ V3 d() const { return rd; }
-    __device__ __forceinline__ void set_d(V3 v) const { rd = v; }
-    __device__ __forceinline__ uint32_t pix() const { return (uint32_t)L.ldi(PC_PIX) & 0x03FFFFFFu; }
-    __device__ __forceinline__ uint32_t frame() const { return (uint32_t)L.ldi(PC_PIX) >> 26; }
-    __device__ __forceinline__ V3 dprim() const { const uint32_t px = pix(); return primary_dir(P, px % P.W, px / P.W); }
-    __device__ __forceinline__ void set_dprim(V3) const {}
-    __device__ __forceinline__ float prim_t() const { return prim_t_[pix()]; }
-    __device__ __forceinline__ void set_prim_t(float) const {}
-    __device__ __forceinline__ int prim_tri() const { return prim_tri_[pix()]; }
-    __device__ __forceinline__ void set_prim_tri(int) const {}
-};
-
-#ifdef PTX_HEAT
-__device__ unsigned int g_heat[1u << 20];    // diagnostic build only: node-visit histogram over all layouts
-#endif
-
 #define PTX_POOL_KEY_NONE ((unsigned long long)0x7e967699u << 32 | 0xFFFFFFFFull)   // bits(1.0e38f) << 32 | 0xFFFFFFFF: "no hit yet"
 
 template <int PRUNE, bool MEMO, bool COUNT>
-__global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
+__global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S, DParams P, const int32_t* __restrict__ timestamps,
                                                     const float* __restrict__ prim_t, const int* __restrict__ prim_tri,
                                                     float4* __restrict__ fb, uint32_t n_frames, uint32_t chunk,
                                                     uint32_t* __restrict__ task_counter, unsigned long long* counters) {
-    // per wave (private; `wv` selects the wave's slice):
-    __shared__ float lds_all[PTX_POOL_WAVES][PC_WORDS * 64];             // path state only (PathLdsC, 24 words per lane); work counters live in scalar registers
-    __shared__ unsigned long long keys_all[PTX_POOL_WAVES][64];          // best (t, slot) of the lane's ray
-    __shared__ uint2 queue_all[PTX_POOL_WAVES][PTX_POOL_QCAP];
-    __shared__ uint32_t kap_all[PRUNE == 1 ? PTX_POOL_WAVES : 1][64];    // PRUNE = 1: packed kappa pair of the lane's ray (ray_kappa), read by whoever tests its leaves
-    __shared__ float tlm_all[PTX_POOL_WAVES][64];                        // PRUNE != 0: light_bound of the lane's ray if it is a light-visibility ray, else -3e38
-    // shared by the workgroup, read-only after the barrier: the hot_k hottest node records of each octant layout
-    __shared__ float4 hot[(PRUNE == 1 || PTX_POOL_HOTK == 0) ? 2 : 8 * PTX_POOL_HOTK * 2];
-    // TAIL requests of the workgroup: bit l of tail_req[w] = the path of lane l of wave w waits for shade_tail (its state is in
-    // that wave's LDS slice); bit l of tail_done[w] = it has been run.  tail_ctl = {requests pending, gather lock}
-    __shared__ unsigned long long tail_req[PTX_POOL_WAVES], tail_done[PTX_POOL_WAVES];
-    __shared__ uint32_t tail_ctl[2], tail_tmp[64];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wv = PTX_POOL_WAVES > 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0u;
-    float* const lds = lds_all[wv];
-    unsigned long long* const keys = keys_all[wv];
-    uint2* const queue = queue_all[wv];
-    uint32_t* const kap = kap_all[PRUNE == 1 ? wv : 0];
-    float* const tlm = tlm_all[wv];
-    if (PRUNE != 1 && S.hot_k != 0u) {               // hot records: layout o, record r, half h  ->  hot[(o * hot_k + r) * 2 + h]
-        const uint32_t per = S.hot_k * 2u;
-        for (uint32_t q = threadIdx.x; q < 8u * per; q += 64u * PTX_POOL_WAVES) {
-            const uint32_t o = q / per, r = q - o * per;
-            hot[q] = ld16(S.nodes, o * S.oct_stride + r * 16u);
-        }
-    }
-    if (threadIdx.x < (uint32_t)PTX_POOL_WAVES) { tail_req[threadIdx.x] = 0ull; tail_done[threadIdx.x] = 0ull; }
-    if (threadIdx.x < 2u) tail_ctl[threadIdx.x] = 0u;
-    __syncthreads();                                 // the only barrier: from here on every wave runs on its own
+    __shared__ float lds[PW_C_SAMPLES * 64];         // path state only (25 words per lane); work counters live in scalar registers
+    __shared__ unsigned long long keys[64];          // best (t, slot) of the lane's ray
+    __shared__ uint2 queue[PTX_POOL_QCAP];
+    __shared__ uint32_t kap[64];                     // PRUNE = 1: packed kappa pair of the lane's ray (ray_kappa), read by whoever tests its leaves
+    __shared__ float tlm[64];                        // PRUNE != 0: light_bound of the lane's ray if it is a light-visibility ray, else -3e38
+    const uint32_t lane = threadIdx.x;
     const LdsLane L{lds + lane};
     const uint32_t npix = P.W * P.H;
     const uint32_t tiles_x = (P.W + 7) >> 3, tiles_y = (P.H + 7) >> 3;
@@ -183,7 +88,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
     auto below = [](unsigned long long m) { return (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
 
     keys[lane] = PTX_POOL_KEY_NONE;
-    unsigned long long cyc[3] = {0, 0, 0}, its[3] = {0, 0, 0}, n_tailp = 0, n_tails = 0, n_spin = 0, cyc_spin = 0;   // COUNT only
+    unsigned long long cyc[3] = {0, 0, 0}, its[3] = {0, 0, 0};
     uint32_t cnt_nodes = 0, cnt_tris = 0, d_walk = 0, d_tri = 0, d_shade = 0, d_walk_s = 0, d_tri_s = 0, d_shade_s = 0;   // COUNT only
 
     int flags = F_ALIVE;
@@ -198,100 +103,17 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
     uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
     uint32_t probed = 0xFFFFFFFFu;                   // fc word of the leaf the cache has already queued for the running ray: the walk skips it
     uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
-    uint32_t hot_off = 0, hot_lim = 0;               // hot_k > 0: LDS byte offset of the ray's octant layout; records below hot_lim are read from LDS
-    uint32_t iter = 0;                               // wave-uniform loop counter (mailbox polling)
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
 
     for (;;) {
-        // tails that other lanes of the workgroup have run for this wave's paths: those lanes go on (at their next SHADE phase).
-        // The mailbox is looked at every PTX_POOL_TAIL_POLL-th iteration (and whenever the wave has nothing else to do): the loop
-        // runs some 18 000 times per frame and wave, and every instruction at its top is paid that often
-        const bool poll = (iter++ & (uint32_t)(PTX_POOL_TAIL_POLL - 1)) == 0u;
-        if (poll && __ballot((flags & F_WAIT) != 0) != 0ull) {
-            const unsigned long long seen = tail_done[wv];                 // one word, the same for every lane
-            const unsigned long long dn = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(seen >> 32)) << 32) |
-                                          (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)seen);
-            if (dn != 0ull) {
-                if (lane == 0) atomicAnd(&tail_done[wv], ~dn);             // only the bits seen: a worker may be adding others right now
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if ((dn >> lane) & 1ull) flags = (flags & ~F_WAIT) | F_RESUME;
-            }
-        }
         const bool trav = (flags & F_TRAV) != 0;
         if (PRUNE && trav && (uint32_t)(keys[lane] >> 32) == 0u) i = 0xFFFFFFFFu;   // settled by a conclusive blocker (distance bits 0): nothing left to walk
         const bool walking = trav && i < N;
-        const bool need_shade = (flags & F_ALIVE) && !(flags & F_WAIT) && !(trav && (i < N || (int32_t)(head - lastpos) < 0));
+        const bool need_shade = (flags & F_ALIVE) && !(trav && (i < N || (int32_t)(head - lastpos) < 0));
         const int nW = __popcll(__ballot(walking)), nS = __popcll(__ballot(need_shade));
         const uint32_t len = tail - head;
-        const bool idle = (nW | nS) == 0 && len == 0;
-        if (idle && __ballot((flags & F_WAIT) != 0) == 0ull) break;
-        // TAIL: the workgroup's pending tails (shade_tail: direct light, bounce, end of sample) are run 64 at a time by whichever
-        // wave gets there first -- once a full batch waits, or at once by a wave that has nothing else to do
-        uint32_t pend = 0;
-        if (poll || idle) pend = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail_ctl[0]);
-        if (pend >= (uint32_t)PTX_POOL_TAIL_BATCH || (idle && pend != 0u)) {
-            uint32_t got = 0;
-            if (lane == 0) got = atomicCAS(&tail_ctl[1], 0u, 1u) == 0u ? 1u : 0u;
-            got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            if (got) {
-                unsigned long long t_ph = 0;
-                if (COUNT) t_ph = __builtin_amdgcn_s_memtime();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // gather up to 64 requests: lane w looks after wave w's mask; request number q of the batch goes to lane q
-                const unsigned long long req = lane < (uint32_t)PTX_POOL_WAVES ? tail_req[lane] : 0ull;
-                unsigned long long claimed = 0ull;                         // lane w: the bits this batch takes from wave w
-                uint32_t taken = 0;
-                for (int w = 0; w < PTX_POOL_WAVES; w++) {
-                    const unsigned long long mw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(req >> 32), w) << 32) |
-                                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)req, w);
-                    if (mw == 0ull || taken >= 64u) continue;
-                    const uint32_t r = taken + below(mw);
-                    const bool take = ((mw >> lane) & 1ull) && r < 64u;
-                    if (take) tail_tmp[r] = ((uint32_t)w << 6) | lane;
-                    const unsigned long long cm = __ballot(take);
-                    if (lane == (uint32_t)w) claimed = cm;
-                    taken += (uint32_t)__popcll(cm);
-                }
-                if (claimed != 0ull) atomicAnd(&tail_req[lane], ~claimed);
-                const bool act = lane < taken;
-                const uint32_t who = act ? tail_tmp[lane] : 0u;
-                if (lane == 0) atomicSub(&tail_ctl[0], taken);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) atomicExch(&tail_ctl[1], 0u);               // the batch is ours: the next one may be gathered
-                int st = SH_TRACE;
-                if (act) {
-                    const LdsLane R{&lds_all[0][0] + (who >> 6) * (uint32_t)(PC_WORDS * 64) + (who & 63u)};
-                    V3 to = mk(0.f, 0.f, 0.f), td = R.ld3(PC_LP);          // the attempt's direction travels in the light-point words
-                    PathLdsC rp{R, to, td, P, prim_t, prim_tri};
-                    LocalCnt cc = {};
-                    st = shade_tail<MEMO>(S, P, rp, (uint32_t)rp.aux(), cc);
-                    if (st == SH_DONE) {
-                        const V3 rgb = path_result(P, rp);
-                        fb[(size_t)rp.frame() * npix + rp.pix()] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
-                    }
-                    R.st3(PC_LP, td);                                      // the new ray's direction (its origin: P, or the camera for a new sample)
-                    rp.set_aux(st);
-                }
-                w_pf += (uint32_t)__popcll(__ballot(act && st == SH_DONE));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (claimed != 0ull) atomicOr(&tail_done[lane], claimed);
-                if (COUNT) {
-                    __builtin_amdgcn_s_waitcnt(0);
-                    const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_ph;
-                    if (lane == 0) { cyc[2] += dt; its[2]++; n_tailp++; n_tails += taken; }   // counted with the SHADE phases
-                }
-                continue;
-            }
-        }
-        if (idle) {                                                        // every lane waits for a tail another wave is running
-            unsigned long long t_sp = 0;
-            if (COUNT) t_sp = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_sleep(4);
-            if (COUNT && lane == 0) { n_spin++; cyc_spin += __builtin_amdgcn_s_memtime() - t_sp; }
-            iter = 0;                                                      // look again at once
-            continue;
-        }
+        if ((nW | nS) == 0 && len == 0) break;
         int phase;   // 0 walk, 1 tri, 2 shade
         if (len >= 64u) phase = 1;
         else {
@@ -340,8 +162,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
             }
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
             const bool ordered = S.oct_stride != 0u && __ballot(w0 && (flags & F_INF)) == 0ull;
-            auto walk = [&](auto MODE, auto LINKS) {
-                constexpr bool HOT = decltype(LINKS)::value;      // hot-first layouts: explicit links, the hottest records in LDS
+            auto walk = [&](auto MODE) {
                 bool w = w0;                                      // trav && i < N, carried from one step to the next
 #pragma nounroll
                 for (int g = 0; g < PTX_POOL_WALK_STEPS; g++) {
@@ -349,35 +170,12 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                     bool push = false;
                     uint32_t item = 0;
                     float tn = 0.f;
-                    // Hot records come from LDS (short latency), the others from memory.  A step that issues both kinds of
-                    // load waits for the slower one, so the two are kept apart: a HOT step moves only the lanes whose record is
-                    // staged; lanes at a cold record wait until PTX_POOL_COLD_MIN of them have gathered (or no hot lane is left),
-                    // then one step serves everybody.
-                    bool act = w, cold_step = true;
-                    if (HOT && PTX_POOL_COLD_MIN > 0) {
-                        const bool hl = w && i < hot_lim;
-                        const unsigned long long mh = __ballot(hl);
-                        cold_step = mh == 0ull || __popcll(__ballot(w && !hl)) >= PTX_POOL_COLD_MIN;
-                        act = cold_step ? w : hl;
-                    }
-                    if (act) {
-                        float4 a, b;
-                        if (HOT && !cold_step) {
-                            const float4* h = (const float4*)((const char*)hot + hot_off + (i << 5));
-                            a = h[0]; b = h[1];
-                        } else if (HOT && i < hot_lim) {
-                            const float4* h = (const float4*)((const char*)hot + hot_off + (i << 5));
-                            a = h[0]; b = h[1];
-                        } else {
-                            a = ld16(S.nodes, nbase + (i << 5));
-                            b = ld16(nodes_hi, nbase + (i << 5));
-                        }
+                    if (w) {
+                        const float4 a = ld16(S.nodes, nbase + (i << 5));
+                        const float4 b = ld16(nodes_hi, nbase + (i << 5));
                         int miss = __float_as_int(b.z), fc = __float_as_int(b.w);
                         asm volatile("" : "+v"(miss), "+v"(fc));     // keep the links in the record's two loads (no third, dependent one)
                         if (COUNT) cnt_nodes++;
-#ifdef PTX_HEAT
-                        atomicAdd(&g_heat[(nbase >> 5) + i], 1u);   // diagnostic build only (tools/dbg/heat.py): visits per node record
-#endif
                         // MODE 0: every walking lane takes the entry-first shortcut; 1: lanes with an infinite 1/d component walk
                         // the reference tree with the selecting test (second-operand NaN rule), the others stay entry-first;
                         // 2: single-layout views (the reference tree for everyone): selecting tests only
@@ -392,8 +190,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                         if (PRUNE == 1) hit = hit && !(fc < 0 && prune_far<1>(tn, limit, (uint32_t)fc, kappa));   // leaves: at dequeue, with their own coefficients
                         push = hit && fc >= 0 && (!PTX_POOL_SKIP_PROBED || (uint32_t)fc != probed);   // internal nodes and empty leaves carry -2: nothing to queue
                         item = (uint32_t)fc;
-                        if (HOT) i = (hit && fc < 0) ? ((uint32_t)fc & 0x7FFFFFFFu) : (uint32_t)miss;   // after a leaf the walk goes on at its miss link
-                        else i = hit ? i + 1u : (uint32_t)miss;
+                        i = hit ? i + 1u : (uint32_t)miss;
                     }
                     const unsigned long long m = __ballot(push);
                     if (push) {
@@ -402,17 +199,14 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                         lastpos = pos + 1u;
                     }
                     tail += (uint32_t)__popcll(m);
-                    if (COUNT) { d_walk += act ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
+                    if (COUNT) { d_walk += w ? 1u : 0u; if (lane == 0) d_walk_s += 64u; }
                     w = trav && i < N;
                     if (__popcll(__ballot(w)) * 8 <= nW * PTX_POOL_WALK_KEEP) break;   // KEEP = 0: only when nobody walks
                 }
             };
-            if (PRUNE != 1 && S.hot_k != 0u) {
-                if (ordered) walk(std::integral_constant<int, 0>{}, std::true_type{});
-                else walk(std::integral_constant<int, 1>{}, std::true_type{});
-            } else if (ordered) walk(std::integral_constant<int, 0>{}, std::false_type{});
-            else if (S.oct_stride != 0u) walk(std::integral_constant<int, 1>{}, std::false_type{});
-            else walk(std::integral_constant<int, 2>{}, std::false_type{});
+            if (ordered) walk(std::integral_constant<int, 0>{});
+            else if (S.oct_stride != 0u) walk(std::integral_constant<int, 1>{});
+            else walk(std::integral_constant<int, 2>{});
         } else if (phase == 1) {
             const uint32_t n = min(len, 64u);
             const bool has = lane < n;
@@ -474,24 +268,10 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
             }
         } else {
             if (COUNT) { d_shade += need_shade ? 1u : 0u; if (lane == 0) d_shade_s += 64u; }
-            bool run_shade = need_shade && (flags & F_TASK) && !(flags & F_RESUME);      // a finished ray (or a pending cached primary hit)
+            bool run_shade = need_shade && (flags & F_TASK);      // a finished ray (or a pending cached primary hit)
             bool want_task = need_shade && !(flags & F_TASK);
             bool start_trav = false;
-            PathLdsC p{L, ro, rd, P, prim_t, prim_tri};
-            // (0) lanes whose tail has been run (TAIL, above): the result code says how the path goes on
-            if (need_shade && (flags & F_RESUME)) {
-                flags &= ~F_RESUME;
-                const int code = p.aux();
-                if (code == SH_DONE) {                                      // the task is finished (the worker wrote its pixel)
-                    flags &= ~(F_TASK | F_TRAV | F_CACHED);
-                    want_task = true;
-                } else {
-                    rd = L.ld3(PC_LP);
-                    if (p.bounce() == 0) ro = P.src;                        // a new sample starts at the camera (path_new_sample)
-                    if (code == SH_CACHED) { flags = (flags | F_CACHED) & ~F_TRAV; run_shade = true; }
-                    else { flags &= ~F_CACHED; start_trav = true; }
-                }
-            }
+            PathLds p{L, ro, rd, P, prim_t, prim_tri};
             // (1) hand out the wave's next tasks (wave-uniform control flow: the cursor `next` stays uniform)
             for (;;) {
                 const unsigned long long m = __ballot(want_task);
@@ -520,7 +300,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                         uint32_t px, py;
                         if (tile_pixel(P, tile, mine & 63u, px, py)) {     // else: padding lane of an edge tile, draw again
                             const uint32_t pix = py * P.W + px;
-                            L.sti(PC_PIX, (int)(pix | (frame << 26))); L.sti(PC_PACK, 0); L.sti(PC_LIS, 0);
+                            L.sti(PW_PIX, (int)(pix | (frame << 26))); L.sti(PW_PACK, 0);
                             LocalCnt cb = {};
                             const int st = path_begin<MEMO>(P, p, px, py, timestamps[frame], 0.f, 0, cb);
                             if (st == SH_DONE) {                            // max_path_length <= 0: black; draw again
@@ -537,55 +317,61 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                 }
                 w_pf += (uint32_t)__popcll(__ballot(black));
             }
-            // (2) consume finished rays / cached primary hits: shade_front draws the next light attempt or hands the path to a tail
+            // (2) consume finished rays / cached primary hits.  A lane may go through several samples in a row (primary ray
+            //     misses or hits an emitter: every sample ends at once); the loop is wave-uniform so the counters stay scalar
             {
                 float t = 0.f;
                 bool hit = false;
                 int tri = -1;
-                if (run_shade) {
-                    if (flags & F_CACHED) {
-                        t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri();
-                    } else {
-                        const unsigned long long key = keys[lane];
-                        t = __uint_as_float((uint32_t)(key >> 32));
-                        hit = t < 1.0e38f;
-                        if (hit) {
-                            const uint32_t slot = (uint32_t)key >> 1;
-                            if (p.stage() != ST_PATH && ((uint32_t)key & 1u) == 0u) {
-                                // a light-visibility ray stopped by a triangle without emission: shade_front needs no index (tri < 0);
-                                // the blocker's leaf is remembered for the next attempt instead
-                                tri = -1;
-                                c_noff = S.ref_base + ((uint32_t)__float_as_int(ld16(S.tris, slot * 48u + 32u).w) << 5);
-                            } else {
-                                tri = __float_as_int(ld16(S.tris, slot * 48u).w);
-                            }
+                bool cached = (flags & F_CACHED) != 0;
+                if (run_shade && !cached) {
+                    const unsigned long long key = keys[lane];
+                    t = __uint_as_float((uint32_t)(key >> 32));
+                    hit = t < 1.0e38f;
+                    if (hit) {
+                        const uint32_t slot = (uint32_t)key >> 1;
+                        if (p.stage() != ST_PATH && ((uint32_t)key & 1u) == 0u) {
+                            // a light-visibility ray stopped by a triangle without emission: shade_step needs no index (tri < 0);
+                            // the blocker's leaf is remembered for the next attempt instead
+                            tri = -1;
+                            c_noff = S.ref_base + ((uint32_t)__float_as_int(ld16(S.tris, slot * 48u + 32u).w) << 5);
+                        } else {
+                            tri = __float_as_int(ld16(S.tris, slot * 48u).w);
                         }
                     }
                 }
-                LocalCnt cc = {};
-                uint32_t tf = 0;
+                bool act = run_shade;
                 int st = SH_TRACE;
-                if (run_shade) st = shade_front<MEMO>(S, P, p, hit, t, tri, cc, tf);
-                // per call: rays 1 or 2 (the memoised shadow ray), hits 0..2, light attempts 0 or 1
-                w_rays += (uint32_t)__popcll(__ballot(cc.rays >= 1u)) + (uint32_t)__popcll(__ballot(cc.rays >= 2u));
-                w_hits += (uint32_t)__popcll(__ballot(cc.ray_hits >= 1u)) + (uint32_t)__popcll(__ballot(cc.ray_hits >= 2u));
-                w_att += (uint32_t)__popcll(__ballot(cc.light_attempts >= 1u));
-                const bool to_tail = run_shade && st == SH_TAIL;
-                if (run_shade) {
+                // PTX_POOL_DEFER_CACHED: a lane whose sample ended meets its cached primary hit in the NEXT shade phase, together
+                // with the other lanes that have a hit to process, instead of a second pass through shade_step for a few lanes now
+                for (int pass = 0; (PTX_POOL_DEFER_CACHED ? pass == 0 : true) && __ballot(act) != 0ull; pass++) {
+                    LocalCnt cc = {};
+                    if (act) {
+                        if (cached) { t = p.prim_t(); hit = t < 1.0e38f; tri = p.prim_tri(); }
+                        st = shade_step<MEMO>(S, P, p, hit, t, tri, cc);
+                        cached = (st == SH_CACHED);
+                        act = cached;
+                    }
+                    // per call: rays 1 or 2 (the memoised shadow ray), hits 0..2, light attempts 0 or 1
+                    w_rays += (uint32_t)__popcll(__ballot(cc.rays >= 1u)) + (uint32_t)__popcll(__ballot(cc.rays >= 2u));
+                    w_hits += (uint32_t)__popcll(__ballot(cc.ray_hits >= 1u)) + (uint32_t)__popcll(__ballot(cc.ray_hits >= 2u));
+                    w_att += (uint32_t)__popcll(__ballot(cc.light_attempts >= 1u));
+                }
+                bool done = false;
+                if (run_shade && st == SH_CACHED) {            // (deferred) needs shade again: no ray in flight
+                    flags = (flags | F_CACHED) & ~F_TRAV;
+                } else if (run_shade) {
                     flags &= ~F_CACHED;
-                    if (to_tail) {
-                        L.st3(PC_LP, rd);                                  // the attempt's direction (the light point itself is no longer needed)
-                        p.set_aux((int)tf);
-                        flags = (flags | F_WAIT) & ~F_TRAV;
+                    if (st == SH_DONE) {
+                        const V3 rgb = path_result(P, p);
+                        fb[(size_t)p.frame() * npix + p.pix()] = make_float4(rgb.x, rgb.y, rgb.z, 1.0f);
+                        done = true;
+                        flags &= ~(F_TASK | F_TRAV);          // takes its next task in the next SHADE phase
                     } else {
                         start_trav = true;
                     }
                 }
-                const unsigned long long mt = __ballot(to_tail);
-                if (mt != 0ull) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the path state is in LDS before the request is
-                    if (lane == 0) { atomicOr(&tail_req[wv], mt); atomicAdd(&tail_ctl[0], (uint32_t)__popcll(mt)); }
-                }
+                w_pf += (uint32_t)__popcll(__ballot(done));
             }
             // (3) start the traversal of the lanes that now hold a fresh ray
             if (start_trav) {
@@ -600,10 +386,7 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
                 const bool deg = inv_degenerate(inv);
                 flags = (flags & ~(F_INF | F_PROBE)) | F_TRAV | (deg ? F_INF : 0);
                 probed = 0xFFFFFFFFu;
-                const uint32_t oc = octant(rd);
-                nbase = deg ? S.ref_base : oc * S.oct_stride;
-                hot_off = oc * (S.hot_k << 5);
-                hot_lim = deg ? 0u : S.hot_k;                 // the reference tree (layout 8) is not staged
+                nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
                 const bool lightray = p.stage() != ST_PATH;
 #if PTX_POOL_CACHE_RESET
                 if (!lightray) c_noff = 0xFFFFFFFFu;         // 1: the cache belongs to the attempts of one bounce
@@ -623,7 +406,6 @@ __global__ __launch_bounds__(64 * PTX_POOL_WAVES, PTX_POOL_MIN_WAVES) void k_ren
     }
     if (COUNT && lane == 0) {
         for (int e = 0; e < 3; e++) { atomicAdd(&counters[CNT_CYC_WALK + e], cyc[e]); atomicAdd(&counters[CNT_IT_WALK + e], its[e]); }
-        atomicAdd(&counters[CNT_TAIL_PASSES], n_tailp); atomicAdd(&counters[CNT_TAILS], n_tails); atomicAdd(&counters[CNT_SPINS], n_spin); atomicAdd(&counters[CNT_CYC_SPIN], cyc_spin);
     }
     LocalCnt c = {};
     if (lane == 0) {   // every task runs exactly spp samples (glsl:521-525), so samples = pixel-frames x spp

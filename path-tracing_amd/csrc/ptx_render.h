@@ -27,7 +27,7 @@ enum { SH_TRACE = 0, SH_CACHED = 1, SH_DONE = 2 };   // what shade_step() wants 
     X3(sum)                  /* sum of the samples' radiance (glsl:524)          */                               \
     X3(dprim) XF(prim_t) XI(prim_tri)   /* primary ray + its cached hit          */                               \
     XI(s)                    /* samples finished                                 */                               \
-    X3(o) X3(d) X3(thr) X3(rad) X3(n) X3(col) X3(lp) XI(lvis) XF(dist) XI(li) XI(attempts) XI(bounce) XI(stage)
+    X3(o) X3(d) X3(thr) X3(rad) X3(n) X3(col) X3(lp) XF(lpdf) XI(li) XI(attempts) XI(bounce) XI(stage)
 
 struct PathRegs {
 #define X3(f) V3 f##_; __device__ __forceinline__ V3 f() const { return f##_; } __device__ __forceinline__ void set_##f(V3 v) { f##_ = v; }
@@ -68,7 +68,7 @@ __device__ __forceinline__ int path_begin(const DParams& P, PT& p, uint32_t px, 
     p.set_prim_t(prim_t); p.set_prim_tri(prim_tri);
     p.set_s(0);
     p.set_n(mk(0.f, 0.f, 0.f)); p.set_col(mk(0.f, 0.f, 0.f)); p.set_lp(mk(0.f, 0.f, 0.f));
-    p.set_lvis(0); p.set_dist(0.0f); p.set_li(0); p.set_attempts(0);
+    p.set_lpdf(1.0f); p.set_li(0); p.set_attempts(0);
     path_new_sample(P, p);
     if (P.max_len <= 0) { c.samples += (uint32_t)P.spp; return SH_DONE; }
     c.samples++;
@@ -82,39 +82,31 @@ __device__ __forceinline__ V3 path_result(const DParams& P, const PT& p) {
     return mk(clamp01(m.x), clamp01(m.y), clamp01(m.z));
 }
 
-// shade_step() consumes the closest hit (hit, t, tri) of the ray (p.o(), p.d()) in stage p.stage() and advances the path.
+// Consumes the closest hit (hit, t, tri) of the ray (p.o(), p.d()) in stage p.stage() and advances the path.
 // Returns SH_TRACE: trace (p.o(), p.d()) next; SH_CACHED: the next hit is the pixel's cached primary hit (call again with
 // it, no traversal); SH_DONE: all samples of the task are finished.
-// It is split in two so that pipeline 2 can run the halves in different places (ptx_pool.h "TAIL"):
-//   shade_front: the common, cheap transitions -- a path hit that starts next-event estimation, a blocked light attempt that
-//                draws the next one (six of seven finished rays).  Everything else it only CLASSIFIES (tail flags TF_*);
-//   shade_tail:  the rare, expensive rest -- direct light (glsl:442-453), the bounce (glsl:459-486), the end of a sample.
-// The tail needs nothing of the ray but the attempt's direction p.d() and its length before normalisation p.dist(): glsl:431-432
-// recompute normalize(lightPoint - P) and length(lightPoint - P) from the values the last attempt used (glsl:385), so the
-// direction IS that attempt's direction and the distance is the square root its normalisation already took.
-enum { SH_TAIL = 3 };
-enum { TF_END = 1 /* the sample ends as it is */, TF_BOUNCE = 2, TF_DIRECT = 4 /* the light sample contributes (glsl:442) */ };
-
 template <bool MEMO, class PT>
-__device__ __forceinline__ int shade_front(const DScene& S, const DParams& P, PT& p, bool hit, float t, int tri, LocalCnt& c, uint32_t& tf) {
+__device__ __forceinline__ int shade_step(const DScene& S, const DParams& P, PT& p, bool hit, float t, int tri, LocalCnt& c) {
     const int L = S.L;
-    tf = 0;
+    bool end_sample = false, do_bounce = false, do_direct = false, sh_hits = false;
+    V3 sh_em = mk(0.f, 0.f, 0.f);
+
     if (p.stage() == ST_PATH) {
         c.rays++;
         if (!hit) {
-            tf = TF_END;                                                  // glsl:487-488
+            end_sample = true;                                            // glsl:487-488
         } else {
             c.ray_hits++;
             const V3 em = mk(S.attrE[tri]);
             p.set_col(mk(S.attrC[tri]));
             if (p.bounce() == 0 && (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f)) {
                 p.set_rad(p.col() * em);                                       // glsl:416-419
-                tf = TF_END;
+                end_sample = true;
             } else {
                 p.set_n(mk(S.attrN[tri]));
                 p.set_o(p.o() + p.d() * t);                                      // glsl:422 (P)
                 if (L > 0) { p.set_attempts(0); p.set_stage(ST_NEE); }
-                else tf = TF_BOUNCE;                                      // L == 0: NEE skipped
+                else do_bounce = true;                                    // L == 0: NEE skipped
             }
         }
     } else if (p.stage() == ST_NEE) {
@@ -124,67 +116,41 @@ __device__ __forceinline__ int shade_front(const DScene& S, const DParams& P, PT
         if (hit) { c.ray_hits++; if (tri >= 0) bem = mk(S.attrE[tri]); }   // tri < 0: a triangle known to have emission (0,0,0) (pipeline 2)
         const bool visible = !(hit && any_ne(bem, lem));                  // glsl:353-363
         if (visible || p.attempts() >= 10) {
-            p.set_lvis(visible ? 1 : 0);                                     // glsl:389-395: pdf = visible ? 1 / (L * area) : 1 (taken in the tail)
+            p.set_lpdf(visible ? S.light[p.li() * 6 + 5].x : 1.0f);            // glsl:389-395
             const V3 nL = mk(S.light[p.li() * 6 + 3]);
             // glsl:431: normalize(lightPoint - P) == the attempt's direction d (same expression)
             if (dot(p.n(), p.d()) > 0.0f && dot(nL, -p.d()) > 0.0f) {           // glsl:435
-                if (MEMO) {                                                // the shadow ray of glsl:439 is this attempt's ray again
-                    c.rays++; if (hit) c.ray_hits++;
-                    const bool lit = !hit || (bem.x != 0.0f || bem.y != 0.0f || bem.z != 0.0f);   // glsl:442
-                    tf = TF_BOUNCE | (lit ? TF_DIRECT : 0);
-                } else {
-                    p.set_stage(ST_SHADOW);                                  // trace glsl:439 for real
-                    return SH_TRACE;
-                }
+                if (MEMO) { c.rays++; if (hit) c.ray_hits++; sh_hits = hit; sh_em = bem; do_direct = true; do_bounce = true; }
+                else p.set_stage(ST_SHADOW);                                 // trace glsl:439 for real
             } else {
-                tf = TF_BOUNCE;
+                do_bounce = true;
             }
         }
         // else: another attempt (generated below)
     } else { // ST_SHADOW (only without MEMO)
         c.rays++;
-        V3 sh_em = mk(0.f, 0.f, 0.f);
         if (hit) { c.ray_hits++; if (tri >= 0) sh_em = mk(S.attrE[tri]); }
-        const bool lit = !hit || (sh_em.x != 0.0f || sh_em.y != 0.0f || sh_em.z != 0.0f);
-        tf = TF_BOUNCE | (lit ? TF_DIRECT : 0);
+        sh_hits = hit;
+        do_direct = true;
+        do_bounce = true;
     }
-    if (tf) return SH_TAIL;
-    // next light attempt (glsl:372-387); p.o() holds P
-    p.set_attempts(p.attempts() + 1);
-    c.light_attempts++;
-    float r0, r1;
-    path_rng(p, r0, r1);
-    int ridx = (int)((float)L * r0);                                  // glsl:375: int(float(L)*r) % L
-    if (ridx >= L) ridx -= L;                                         // only r == 1.0 reaches L
-    p.set_li(ridx);
-    path_rng(p, r0, r1);                                        // glsl:339-351
-    if (r0 + r1 > 1.0f) { r0 = 1.0f - r0; r1 = 1.0f - r1; }
-    const V3 v0 = mk(S.light[p.li() * 6 + 0]), v1 = mk(S.light[p.li() * 6 + 1]), v2 = mk(S.light[p.li() * 6 + 2]);
-    p.set_lp((v0 * ((1.0f - r0) - r1) + v1 * r0) + v2 * r1);             // glsl:383
-    const V3 v = p.lp() - p.o();
-    const float len = sqrtf(dot(v, v));                               // glsl:432 length(lightPoint - P), kept for the tail
-    p.set_dist(len);
-    p.set_d(v * (1.0f / len));                                        // glsl:385 normalize(lightPoint - P)
-    return SH_TRACE;
-}
 
-template <bool MEMO, class PT>
-__device__ __forceinline__ int shade_tail(const DScene& S, const DParams& P, PT& p, uint32_t tf, LocalCnt& c) {
-    bool end_sample = (tf & TF_END) != 0;
-    if (tf & TF_DIRECT) {                                                 // glsl:442-453
-        const V3 nL = mk(S.light[p.li() * 6 + 3]);
-        const V3 lem = mk(S.light[p.li() * 6 + 4]);
-        const float dist = p.dist();
-        const float lpdf = p.lvis() ? S.light[p.li() * 6 + 5].x : 1.0f;      // glsl:389-395
-        const float sa = fmaxf(dot(nL, -p.d()), 0.0f) / (dist * dist);
-        const V3 brdf = (p.col() * PTX_M_1_PI) * dot(p.n(), p.d());
-        const V3 direct = (lem * sa) * brdf;
-        const float bpdf = lpdf * sa;
-        const float f1 = lpdf * lpdf, f2 = bpdf * bpdf;
-        const float w = f1 / (f1 + f2);
-        p.set_rad(p.rad() + ((p.thr() * w) * direct) / lpdf);
+    if (do_direct) {                                                      // glsl:442-453
+        if (!sh_hits || (sh_em.x != 0.0f || sh_em.y != 0.0f || sh_em.z != 0.0f)) {
+            const V3 nL = mk(S.light[p.li() * 6 + 3]);
+            const V3 lem = mk(S.light[p.li() * 6 + 4]);
+            const float dist = length(p.lp() - p.o());
+            const float sa = fmaxf(dot(nL, -p.d()), 0.0f) / (dist * dist);
+            const V3 brdf = (p.col() * PTX_M_1_PI) * dot(p.n(), p.d());
+            const V3 direct = (lem * sa) * brdf;
+            const float bpdf = p.lpdf() * sa;
+            const float f1 = p.lpdf() * p.lpdf(), f2 = bpdf * bpdf;
+            const float w = f1 / (f1 + f2);
+            p.set_rad(p.rad() + ((p.thr() * w) * direct) / p.lpdf());
+        }
     }
-    if (tf & TF_BOUNCE) {                                                 // glsl:459-486
+
+    if (do_bounce) {                                                      // glsl:459-486
         float r0, r1;
         path_rng(p, r0, r1);
         const V3 nd = sample_hemisphere(r0, r1, p.n());
@@ -207,6 +173,7 @@ __device__ __forceinline__ int shade_tail(const DScene& S, const DParams& P, PT&
             else p.set_stage(ST_PATH);
         }
     }
+
     if (end_sample) {
         p.set_sum(p.sum() + p.rad());                                            // glsl:524
         p.set_s(p.s() + 1);
@@ -215,14 +182,22 @@ __device__ __forceinline__ int shade_tail(const DScene& S, const DParams& P, PT&
         path_new_sample(P, p);
         return MEMO ? SH_CACHED : SH_TRACE;
     }
+    if (p.stage() == ST_NEE && !do_bounce) {
+        // next light attempt (glsl:372-387); p.o() holds P
+        p.set_attempts(p.attempts() + 1);
+        c.light_attempts++;
+        float r0, r1;
+        path_rng(p, r0, r1);
+        int ridx = (int)((float)L * r0);                                  // glsl:375: int(float(L)*r) % L
+        if (ridx >= L) ridx -= L;                                         // only r == 1.0 reaches L
+        p.set_li(ridx);
+        path_rng(p, r0, r1);                                        // glsl:339-351
+        if (r0 + r1 > 1.0f) { r0 = 1.0f - r0; r1 = 1.0f - r1; }
+        const V3 v0 = mk(S.light[p.li() * 6 + 0]), v1 = mk(S.light[p.li() * 6 + 1]), v2 = mk(S.light[p.li() * 6 + 2]);
+        p.set_lp((v0 * ((1.0f - r0) - r1) + v1 * r0) + v2 * r1);             // glsl:383
+        p.set_d(normalize(p.lp() - p.o()));                                      // glsl:385
+    }
     return SH_TRACE;
-}
-
-template <bool MEMO, class PT>
-__device__ __forceinline__ int shade_step(const DScene& S, const DParams& P, PT& p, bool hit, float t, int tri, LocalCnt& c) {
-    uint32_t tf;
-    const int st = shade_front<MEMO>(S, P, p, hit, t, tri, c, tf);
-    return st == SH_TAIL ? shade_tail<MEMO>(S, P, p, tf, c) : st;
 }
 
 // One (pixel, frame) task, one lane, rays traced one after the other (pipeline 0).

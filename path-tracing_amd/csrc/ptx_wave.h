@@ -57,7 +57,7 @@ namespace ptx {
 // o and d are the lane's ray registers; dprim / prim_t / prim_tri are recomputed / reloaded from the pixel index.
 enum { PW_SX = 0, PW_SY, PW_SUM, PW_S = PW_SUM + 3, PW_THR, PW_RAD = PW_THR + 3, PW_N = PW_RAD + 3, PW_COL = PW_N + 3, PW_LP = PW_COL + 3,
        PW_LPDF = PW_LP + 3, PW_LI, PW_PACK /* attempts | stage << 8 | bounce << 16 */, PW_PIX /* pixel | frame-in-batch << 26 */,
-       PW_DIST /* length(lightPoint - P) of the last light attempt */, PW_C_SAMPLES, PW_C_RAYS, PW_C_TRACED, PW_C_HITS, PW_C_ATT, PW_C_PF, PW_WORDS };
+       PW_C_SAMPLES, PW_C_RAYS, PW_C_TRACED, PW_C_HITS, PW_C_ATT, PW_C_PF, PW_WORDS };
 
 struct LdsLane {
     float* base;   // &lds[lane]
@@ -80,7 +80,7 @@ struct PathLds {
 #define XI(f, W) __device__ __forceinline__ int f() const { return L.ldi(W); } __device__ __forceinline__ void set_##f(int v) const { L.sti(W, v); }
 #define XU(f, W) __device__ __forceinline__ uint32_t f() const { return (uint32_t)L.ldi(W); } __device__ __forceinline__ void set_##f(uint32_t v) const { L.sti(W, (int)v); }
     XU(sx, PW_SX) XU(sy, PW_SY) X3(sum, PW_SUM) XI(s, PW_S) X3(thr, PW_THR) X3(rad, PW_RAD) X3(n, PW_N) X3(col, PW_COL) X3(lp, PW_LP)
-    XI(lvis, PW_LPDF) XF(dist, PW_DIST) XI(li, PW_LI)
+    XF(lpdf, PW_LPDF) XI(li, PW_LI)
 #undef X3
 #undef XF
 #undef XI
@@ -97,11 +97,8 @@ struct PathLds {
     __device__ __forceinline__ void set_prim_t(float) const {}
     __device__ __forceinline__ int prim_tri() const { return prim_tri_[pix()]; }
     __device__ __forceinline__ void set_prim_tri(int) const {}
-    __device__ __forceinline__ int attempts() const { return L.ldi(PW_PACK) & 0x0F; }                       // <= 10 (glsl:372)
-    __device__ __forceinline__ void set_attempts(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & ~0x0F) | (v & 0x0F)); }
-    // pipeline 2: tail flags on the way to a TAIL pass, its result code on the way back (bits 4 .. 7)
-    __device__ __forceinline__ int aux() const { return (L.ldi(PW_PACK) >> 4) & 0x0F; }
-    __device__ __forceinline__ void set_aux(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & ~0xF0) | ((v & 0x0F) << 4)); }
+    __device__ __forceinline__ int attempts() const { return L.ldi(PW_PACK) & 0xFF; }
+    __device__ __forceinline__ void set_attempts(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & ~0xFF) | (v & 0xFF)); }
     __device__ __forceinline__ int stage() const { return (L.ldi(PW_PACK) >> 8) & 0xFF; }
     __device__ __forceinline__ void set_stage(int v) const { L.sti(PW_PACK, (L.ldi(PW_PACK) & ~0xFF00) | ((v & 0xFF) << 8)); }
     __device__ __forceinline__ int bounce() const { return (int)((uint32_t)L.ldi(PW_PACK) >> 16); }
@@ -109,8 +106,7 @@ struct PathLds {
 };
 
 enum { F_ALIVE = 1, F_TASK = 2, F_TRAV = 4, F_CACHED = 8, F_INF = 16 /* 1/d has an infinite or NaN component */,
-       F_PROBE = 32 /* pipeline 2: a light ray that has not yet tested the box of its blocker-cache leaf */,
-       F_WAIT = 64 /* pipeline 2: the path waits for a TAIL pass (no ray in flight) */, F_RESUME = 128 /* its tail has been run */ };
+       F_PROBE = 32 /* pipeline 2: a light ray that has not yet tested the box of its blocker-cache leaf */ };
 
 template <int PRUNE, bool MEMO, bool COUNT>
 __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S, DParams P, const int32_t* __restrict__ timestamps,
