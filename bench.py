@@ -275,12 +275,14 @@ def main():
 
     # one-off costs that the timed region does not contain: the first call fills the per-pixel primary-hit cache (k_primary, once
     # per camera), allocates the frame buffers and loads the code object
-    t0 = time.perf_counter()
-    run(my_frames(0, world))
-    first_call_ms = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter()
-    run(my_frames(0, world))
-    second_call_ms = (time.perf_counter() - t0) * 1e3
+    first_call_ms = second_call_ms = None
+    if not args.no_extras:                          # (profiling runs skip it: one launch per frame count there)
+        t0 = time.perf_counter()
+        run(my_frames(0, world))
+        first_call_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        run(my_frames(0, world))
+        second_call_ms = (time.perf_counter() - t0) * 1e3
     if W > 0:
         run(my_frames(0, W * world))
     # ---- the timed region

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps ${PROF_STEPS:-32} --warmup 1 --no-cpu-baseline $@"
+BENCH="python3 $R/bench.py --steps ${PROF_STEPS:-32} --warmup 1 --no-cpu-baseline --no-extras $@"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 echo "trace pass done"
 i=0
