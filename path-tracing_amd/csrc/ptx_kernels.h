@@ -110,7 +110,7 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
 // ---- best-t pruning (option "traversal" bit 0).  The reference never prunes (glsl:207-249), so a node may only be skipped
 // when NO triangle beneath it can produce a computed t below the best one found so far.  Template parameter PRUNE:
 //   0  no pruning
-//   1  PROVABLE pruning (default; DESIGN.md "Pruning and exactness").  For a hit the triangle test accepts, the point
+//   1  PROVABLE pruning (option "prune" = 1; DESIGN.md "Pruning and exactness").  For a hit the triangle test accepts, the point
 //      o + t_computed * d lies within rho of the triangle, hence of every box around it, where (rounding-error analysis of
 //      glsl:150-173; host: prune_coefs)
 //          rho <= c_o * M_ray                      for ANY triangle: the accepted determinant is >= 1e-4 in magnitude (glsl:156)
@@ -126,8 +126,9 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
 //      largest coefficients beneath the node (every triangle counts in exactly one of the two): inner nodes carry them in
 //      fc (see the layout above), leaves in their first triangle / pair record.  Rays with an infinite 1/d component, rays
 //      that are not unit length and rays from far outside the scene get kappa = inf and are never pruned.
-//   2  heuristic margin  tn > best * (1 + 1e-3) + 1e-3  (option "prune" = 2): faster, but NOT exact -- rays that graze a
-//      large triangle can lose it (ptx_selfcheck_pruning finds such rays); for previews.
+//   2  heuristic margin  tn > best * (1 + 1e-3) + 1e-3  (option "prune" = 2, the library default): faster, but NOT exact for
+//      every conceivable ray -- rays that graze a large triangle can lose it (ptx_selfcheck_pruning constructs such rays; none
+//      occurs in the frames compared so far, include/ptx.h "prune").
 #define PTX_PRUNE_REL 0.001f
 #define PTX_PRUNE_ABS 0.001f
 #define PTX_PRUNE_SAFE_REL 1.52587890625e-05f   // 2^-16: covers the three roundings of a computed slab entry distance
