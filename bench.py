@@ -334,12 +334,13 @@ def main():
         if not default_kernel:
             prof = None
         stale = None
-        if prof and prof.get("kernel_ms_per_frame"):
-            drift = kernel_ms_per_frame / prof["kernel_ms_per_frame"] - 1.0
-            stale = {"stale": abs(drift) > STALE_TOLERANCE, "profile_kernel_ms_per_frame": prof["kernel_ms_per_frame"], "run_kernel_ms_per_frame": kernel_ms_per_frame,
+        prof_ms = (prof or {}).get("kernel_ms_per_frame_timed_launch") or (prof or {}).get("kernel_ms_per_frame")
+        if prof_ms:
+            drift = kernel_ms_per_frame / prof_ms - 1.0
+            stale = {"stale": abs(drift) > STALE_TOLERANCE, "profile_kernel_ms_per_frame": prof_ms, "run_kernel_ms_per_frame": kernel_ms_per_frame,
                      "drift": drift, "tolerance": STALE_TOLERANCE}
             if stale["stale"]:
-                print(f"bench.py: WARNING: {prof_file} was taken at {prof['kernel_ms_per_frame']:.2f} ms per frame, this run measures {kernel_ms_per_frame:.2f} "
+                print(f"bench.py: WARNING: {prof_file} was taken at {prof_ms:.2f} ms per frame, this run measures {kernel_ms_per_frame:.2f} "
                       f"({drift:+.1%}): the counter-derived roofline figures are STALE -- re-run tools/profile.sh", file=sys.stderr, flush=True)
         valu = None
         if prof and "valu" in prof:

@@ -15,11 +15,11 @@ lines = []
 db = sqlite3.connect(os.path.join(base, "trace", "trace_results.db"))
 lines.append("== kernel stats (rocprofv3 --kernel-trace --stats; durations in ns) ==")
 lines.append(f"{'kernel':<70} {'calls':>6} {'total_ns':>16} {'avg_ns':>16} {'min_ns':>14} {'max_ns':>14}")
-kern_ns, kern_calls, prim_ms = 0.0, 0, None
+kern_ns, kern_calls, prim_ms, kern_max = 0.0, 0, None, 0.0
 for r in db.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by name order by 3 desc").fetchall():
     lines.append(f"{r[0][:70]:<70} {r[1]:>6} {r[2]:>16.0f} {r[3]:>16.0f} {r[4]:>14.0f} {r[5]:>14.0f}")
     if IS_RENDER.search(r[0]):
-        kern_ns, kern_calls = float(r[2]), int(r[1])
+        kern_ns, kern_calls, kern_max = float(r[2]), int(r[1]), float(r[5])
     if "k_primary" in r[0]:
         prim_ms = float(r[3]) / 1e6
 lines.append("")
@@ -59,6 +59,8 @@ open(os.path.join("profiles", f"{tag}_kernel_stats.txt"), "w").write("\n".join(l
 per_frame = {k: v[1] / frames for k, v in tot.items()}
 out = {"source": f"gpurun_out/prof_{tag}: rocprofv3 --kernel-trace [--stats | --pmc <one group per pass>] -- python3 bench.py --steps {frames - 1} --warmup 1 --no-cpu-baseline",
        "frames": frames, "kernel_launches": kern_calls, "kernel_ns_total": kern_ns, "kernel_ms_per_frame": kern_ns / 1e6 / frames if frames else None,
+       # the timed launch alone (the run's largest: frames - 1 frames behind a one-frame warm-up launch): what bench.py's stale check compares
+       "kernel_ms_per_frame_timed_launch": kern_max / 1e6 / (frames - 1) if frames > 1 and kern_calls == 2 else None,
        "per_frame": per_frame, "calibration": calib, "one_off": {"k_primary_ms": prim_ms}}
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     out["hbm"] = {"correction": "FETCH_SIZE x2 (gfx950), KB -> B; WRITE_SIZE KB -> B", "fetch_bytes_per_frame": 2.0 * per_frame["FETCH_SIZE"] * 1024.0,
