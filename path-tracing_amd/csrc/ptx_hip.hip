@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void k_selfcheck(DScene S, CheckArgs A, CheckOu
         if (emitter && !inv_degenerate(inv)) {
             Kappa kap = {0.f, 0.f};
             if (PRUNE == 1) kap = unpack_kappa(pack_kappa(ray_kappa(S, o, d)));
-            violation = prune_far<PRUNE>(light_bound<PRUNE>(S, o, inv, kap), prune_limit<PRUNE>(t0), S.lcoefs, kap);
+            violation = light_settles<PRUNE>(S, light_bound<PRUNE>(S, o, d, inv, kap), t0, kap);
         }
     }
     const unsigned long long mh = __ballot(h0), mb = __ballot(bad), ma = __ballot(1), me = __ballot(emitter), mv = __ballot(violation);
@@ -350,6 +350,10 @@ struct ptx_ctx {
     const uint32_t* d_big_slots = nullptr;                     // inorder slots of the largest triangles, by area
     const uint32_t* d_emit_slots = nullptr;                    // inorder slots of the triangles with a non-zero emission (selfcheck families 8 .. 11)
     uint32_t n_emit_slots = 0;
+    const float4* d_emit_list = nullptr;                       // provable any-hit rule: (e2 x e1) / n per emissive triangle (at most PTX_MAX_EMIT; ptx_kernels.h light_bound)
+    uint32_t n_emit_list = 0;
+    float emit_c1 = 0.f;
+    int opt_emit_list = 1;                                     // option "emit_list": 0 = the provable rule bounds the emitters by their largest coefficients only (round 2)
     uint32_t n_big_slots = 0;
 
     // params
@@ -421,7 +425,12 @@ static inline DScene scene_view(const ptx_ctx* c) {
     if (!c->opt_anyhit) S.n_lbox = 0;              // (kernels without pruning never look at the boxes)
     // provable rule: with emitters whose position-error coefficient is this large the bound never lets a ray stop (pixar_room's
     // lamp: c_o = 0.054, slack = c_o * kappa of several scene units), and computing it would only cost time
-    if (prune_mode(c) == 1 && !(__uint_as_float_host(S.lcoefs & 0x7FFF0000u) <= 0.01f)) S.n_lbox = 0;
+    // -- unless the scene has few enough emitters for the per-ray bound (light_bound, emitter list), which does not depend on it
+    S.emit = nullptr; S.n_emit = 0; S.emit_c1 = 0.f;
+    if (prune_mode(c) == 1) {
+        if (c->d_emit_list && c->n_emit_list > 0 && c->opt_emit_list) { S.emit = c->d_emit_list; S.n_emit = c->n_emit_list; S.emit_c1 = c->emit_c1; }
+        else if (!(__uint_as_float_host(S.lcoefs & 0x7FFF0000u) <= 0.01f)) S.n_lbox = 0;
+    }
     return S;
 }
 
@@ -1248,8 +1257,29 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     for (uint32_t k = 0; k < T; k++) if (slot_emits[k]) emit_slots.push_back(k);
     ctx->n_emit_slots = (uint32_t)emit_slots.size();
     if (emit_slots.empty()) emit_slots.push_back(0);            // upload() wants a non-empty buffer
+    // the emitter list of the provable any-hit rule (ptx_kernels.h light_bound): G' = (e2 x e1) / n, n = 1.01 * 90 u E^2, in double from
+    // the f32 edges the kernels use, rounded once
+    std::vector<float4> emit_list;
+    double e_min = INFINITY;
+    if (ctx->n_emit_slots > 0 && ctx->n_emit_slots <= PTX_MAX_EMIT) {
+        for (uint32_t q = 0; q < ctx->n_emit_slots; q++) {
+            const uint32_t k = emit_slots[q];
+            const float4 e1 = tris[3 * (size_t)k + 1], e2 = tris[3 * (size_t)k + 2];
+            const double gx = (double)e2.y * e1.z - (double)e1.y * e2.z, gy = (double)e2.z * e1.x - (double)e1.z * e2.x, gz = (double)e2.x * e1.y - (double)e1.x * e2.y;
+            const double l1 = std::sqrt((double)e1.x * e1.x + (double)e1.y * e1.y + (double)e1.z * e1.z), l2 = std::sqrt((double)e2.x * e2.x + (double)e2.y * e2.y + (double)e2.z * e2.z);
+            const double E = std::max(l1, l2), n = 1.01 * 90.0 * kU * E * E;
+            if (!(E > 0.0) || !std::isfinite(E) || !std::isfinite(gx / n) || !std::isfinite(gy / n) || !std::isfinite(gz / n)) { emit_list.clear(); break; }   // degenerate: no list
+            e_min = std::min(e_min, E);
+            emit_list.push_back(make_float4((float)(gx / n), (float)(gy / n), (float)(gz / n), 0.f));
+        }
+    }
+    const float emit_c1 = emit_list.empty() ? 0.f : std::nextafter((float)(0.672 / e_min), INFINITY);
+    ctx->n_emit_list = (uint32_t)emit_list.size();
+    ctx->emit_c1 = emit_c1;
+    ctx->d_emit_list = nullptr;
     DScene S = {};
     int rc;
+    if (!emit_list.empty() && (rc = upload(ctx, emit_list, &ctx->d_emit_list))) { free_scene(ctx); return rc; }
     const std::vector<float4> ref_nodes = nodes;      // {min.xyz, miss}, {max.xyz, fc}: becomes layout 8 behind the octant layouts
     repack_nodes(nodes);
     if ((rc = upload(ctx, nodes, &S.nodes)) || (rc = upload(ctx, tris, &S.tris)) || (rc = upload(ctx, pairs, &S.pairs)) || (rc = upload(ctx, aN, &S.attrN)) ||
@@ -1352,6 +1382,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     else if (k == "prune" && (value == 1 || value == 2)) { ctx->opt_prune = (int)value; ctx->prim_valid = false; }
     else if (k == "overlap" && (value == 0 || value == 1)) ctx->opt_overlap = (int)value;
     else if (k == "anyhit" && (value == 0 || value == 1)) ctx->opt_anyhit = (int)value;
+    else if (k == "emit_list" && (value == 0 || value == 1)) ctx->opt_emit_list = (int)value;
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;

@@ -20,7 +20,9 @@
 
 namespace ptx {
 
+#ifndef PTX_MAX_CLS
 #define PTX_MAX_CLS 8
+#endif
 #ifndef PTX_MAX_LBOX
 #define PTX_MAX_LBOX 4      // boxes around the emissive triangles (light_bound): any-hit termination of light-visibility rays
 #endif
@@ -47,7 +49,14 @@ struct DScene {
     // emission (padded for the margin rule), and the largest pruning coefficients among those triangles
     uint32_t n_lbox, lcoefs;
     float lbox[PTX_MAX_LBOX][6];   // min.xyz, max.xyz
+    // provable rule only (PRUNE = 1), scenes with at most PTX_MAX_EMIT emissive triangles: per emitter {(e2 x e1) / n, 0} with
+    // n = 1.01 * 90 u E^2 (light_bound): the determinant the shader's triangle test will compute for THIS ray is bounded from
+    // below per emitter, instead of by the shader's 1e-4 cut-off for all of them.  emit_c1 = 0.672 / min_k E_k
+    const float4* emit;
+    uint32_t n_emit;
+    float emit_c1;
 };
+#define PTX_MAX_EMIT 32
 
 struct DParams {
     uint32_t W, H;
@@ -179,10 +188,27 @@ __device__ __forceinline__ Kappa unpack_kappa(uint32_t w) { Kappa k; k.k = __uin
 // triangles instead of BVH nodes (the rule only needs a box that contains the triangle).  A box may be left out when the
 // ray cannot hit anything in it: PRUNE = 2, boxes padded on upload: the slab test misses it; PRUNE = 1 (provable): it lies
 // wholly behind the ray even after growing it by the position-error bound (t <= tFar + slack and t > 0 for any hit).
+// PRUNE = 1 with an emitter list (S.n_emit > 0): the slack is computed for the ray at hand.  The lemma (DESIGN.md "Pruning and
+// exactness") bounds the distance of an accepted hit's computed point from its triangle by rho = (u / |a^|) 90 E^2 M + 20 u M,
+// where a^ is the determinant tri_test computes, provided 61 u M E <= |a^|.  a^ is within 7 u E^2 of d . (e2 x e1).  The host
+// stores G' = fl((e2 x e1) / n) with n = 1.01 * 90 u E^2, so r = |fl(d . G')| is |a^| / n to within (7 + 3.1 + 1) u E^2 / n = 0.122
+// (rounding of the dot product and of G' included); with c0 = 0.1761 (16 u E^2 / n), r - c0 <= |a^| / n.  The ray's coefficient
+// per unit of M is max_k n_k / |a^_k| + 1.01 * 20 u <= 1 / (min_k r_k - c0) + 1.21e-6, its slack that times kappa
+// (M max|1/d_k|), as for the per-node coefficients; the lemma's premise 61 u M E_k <= |a^_k| holds for every emitter when
+// min_k r_k - c0 >= M * 0.672 / min_k E_k (61 / (1.01 * 90) = 0.671).  A ray that grazes an emitter fails that and never ends early.
 template <int PRUNE>
-__device__ __forceinline__ float light_bound(const DScene& S, V3 o, V3 inv, Kappa kap) {
+__device__ __forceinline__ float light_bound(const DScene& S, V3 o, V3 d, V3 inv, Kappa kap) {
     float tl = 3.0e38f;
-    const float slack = PRUNE == 1 ? coef_other(S.lcoefs) * kap.k + coef_class(S.lcoefs) * kap.k2 : 0.0f;
+    float slack = PRUNE == 1 ? coef_other(S.lcoefs) * kap.k + coef_class(S.lcoefs) * kap.k2 : 0.0f;
+    const bool listed = PRUNE == 1 && S.n_emit != 0u;
+    if (listed) {
+        const float M = (((fabsf(o.x - S.center.x) + fabsf(o.y - S.center.y)) + fabsf(o.z - S.center.z)) + S.two_rs) * 1.0001f;
+        float rmin = 3.0e38f;
+        for (uint32_t k = 0; k < S.n_emit; k++) rmin = fminf(rmin, fabsf(dot(d, mk(S.emit[k]))));
+        rmin = rmin - 0.1761f;
+        const bool ok = rmin >= M * S.emit_c1;                             // false for NaN
+        slack = ok ? ((__builtin_amdgcn_rcpf(rmin) * 1.001f + 1.21e-6f) * kap.k) * 1.001f : __builtin_inff();
+    }
     for (uint32_t k = 0; k < S.n_lbox; k++) {
         const float* b = S.lbox[k];
         const float ax = (b[0] - o.x) * inv.x, bx = (b[3] - o.x) * inv.x;
@@ -193,7 +219,13 @@ __device__ __forceinline__ float light_bound(const DScene& S, V3 o, V3 inv, Kapp
         const bool out = PRUNE == 2 ? (tn > tf || tf <= 0.0f) : (tf * (1.0f - PTX_PRUNE_SAFE_REL) + slack < 0.0f);   // false for NaN
         if (!out) tl = fminf(tl, tn);
     }
-    return tl;
+    return listed ? tl - slack : tl;      // the listed slack is already in the distance (light_settles)
+}
+// does a blocker at distance tb settle a light-visibility ray whose light_bound is tl?
+template <int PRUNE>
+__device__ __forceinline__ bool light_settles(const DScene& S, float tl, float tb, Kappa kap) {
+    if (PRUNE == 1 && S.n_emit != 0u) return tl > prune_limit<1>(tb);     // false for NaN and -inf
+    return prune_far<PRUNE>(tl, prune_limit<PRUNE>(tb), S.lcoefs, kap);
 }
 
 // 32-bit byte offsets from a uniform base: lets the compiler use the SGPR-base + VGPR-offset addressing form.

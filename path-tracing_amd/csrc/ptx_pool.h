@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 if (PRUNE && S.n_lbox != 0u && (bk & 1u) == 0u) {
                     Kappa ok = {0.f, 0.f};
                     if (PRUNE == 1) ok = unpack_kappa(kap[owner]);
-                    if (prune_far<PRUNE>(tlm[owner], prune_limit<PRUNE>(bt), S.lcoefs, ok)) bt = 0.0f;
+                    if (light_settles<PRUNE>(S, tlm[owner], bt, ok)) bt = 0.0f;
                 }
                 atomicMin(&keys[owner], ((unsigned long long)__float_as_uint(bt) << 32) | (unsigned long long)bk);
             }
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 if (!lightray) c_noff = 0xFFFFFFFFu;         // 1: the cache belongs to the attempts of one bounce
 #endif
                 if (PRUNE && S.n_lbox != 0u) {               // glsl:353-363 / 439-442: only "hit" and the closest hit's emission are used
-                    tlm[lane] = (lightray && !deg) ? light_bound<PRUNE>(S, ro, inv, unpack_kappa(pk)) : -3.0e38f;
+                    tlm[lane] = (lightray && !deg) ? light_bound<PRUNE>(S, ro, rd, inv, unpack_kappa(pk)) : -3.0e38f;
                     if (lightray && !deg && c_noff != 0xFFFFFFFFu) flags |= F_PROBE;   // blocker cache: tested when the walk starts
                 }
             }

@@ -156,3 +156,29 @@ def test_heuristic_margin_is_not_exact_and_the_checker_sees_it(ptx, ctx):
         found += r["mismatches"]
         assert r["mismatches"] < r["rays"] // 10_000          # rare even among adversarial rays
     assert found > 0
+
+
+def test_provable_anyhit_with_the_emitter_list(ptx, orc, ctx):
+    """Round 3: under the provable rule, scenes with at most 32 emissive triangles bound each emitter's determinant for the ray
+    at hand (option "emit_list", default on; ptx_kernels.h light_bound) instead of by the shader's 1e-4 cut-off -- which on
+    pixar_room (a lamp of 19 triangles with edges of a scene unit) had switched the any-hit rule off.  Same bits and reference
+    counters as the oracle with the list on and off; with it, light rays do end early on pixar_room."""
+    name = "pixar_room"
+    s = ptx.load_scene(name)
+    p = ptx.config_params(name, 96, 54, 4, 6)
+    ts = ptx.scene.timestamps(2)
+    want, oc = orc.render_frames(s, p, ts)
+    ctx.upload_scene(s); ctx.set_params(p)
+    visits = {}
+    for emit_list in (0, 1):
+        for k, v in dict(pipeline=2, traversal=3, prune=1, count=1, emit_list=emit_list).items():
+            ctx.set_option(k, v)
+        ctx.reset_accum(); ctx.reset_counters()
+        ctx.render_frames(ts)
+        assert (np.ascontiguousarray(ctx.read_sum()).view(np.uint32) == want.view(np.uint32)).all(), emit_list
+        c = ctx.counters()
+        for key in ("samples", "rays", "ray_hits", "light_attempts"):
+            assert c[key] == oc[key], (key, emit_list)
+        visits[emit_list] = c["node_visits"]
+    ctx.set_option("emit_list", 1)
+    assert visits[1] < 0.8 * visits[0], visits
