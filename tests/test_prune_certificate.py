@@ -9,7 +9,7 @@ Three statements, each with its test (DESIGN.md "Pruning and exactness"):
   * the default margin rule (option "prune" = 2) is NOT exact for every conceivable ray and the same generator shows it: family
     3 (grazing a large triangle from afar) finds rays whose closest hit it loses -- kept as a known-answer test of the
     checker and as the measure of the caveat include/ptx.h states.
-  * on the rays a render really traces the default rule has never changed a bit: 16 whole headline frames (11 G rays) are
+  * on the rays a render really traces the default rule has never changed a bit: the whole headline job (64 frames, 44 G rays) is
     compared here between the default and the unpruned walk, every pixel of every frame bit for bit (one frame of every
     BASELINE configuration in tests/test_gpu_parity.py::test_full_size_properties); and primary rays are never pruned at all."""
 import numpy as np
@@ -105,28 +105,32 @@ def test_provable_pruning_frames_bit_exact(ptx, orc, ctx, pipeline):
         assert (ctx.read_sum().view(np.uint32) == want.view(np.uint32)).all(), (name, traversal)
 
 
-def test_default_rule_on_rendered_rays_16_headline_frames(ptx, ctx):
+def test_default_rule_on_the_whole_headline_job_64_frames(ptx, ctx):
+    """The north_star job itself -- pixar_room 1920x1080, 64 frames x 16 spp, 8 bounces, 44 G reference rays -- frame by frame
+    (a differing frame cannot hide in a sum): the default margin rule, the provable rule and the unpruned walk give the same
+    bits in every pixel of every frame."""
     c = ptx.CONFIGS["headline"]
     ctx.upload_scene(ptx.load_scene(c["scene"]))
     ctx.set_params(ptx.config_params(c["scene"], c["width"], c["height"], c["sample_count"], c["max_path_length"]))
     ctx.set_option("pipeline", 2)
     rays = 0
-    for f0 in range(0, 16, 4):                               # frame by frame: a differing frame cannot hide in a sum
+    for f0 in range(0, c["frames"], 8):
         imgs = {}
-        for mode, opts in (("default", dict(traversal=3, prune=2)), ("unpruned", dict(traversal=2))):
+        for mode, opts in (("default", dict(traversal=3, prune=2)), ("provable", dict(traversal=3, prune=1)), ("unpruned", dict(traversal=2, prune=2))):
             for k, v in opts.items():
                 ctx.set_option(k, v)
             per_frame = []
-            for f in range(f0, f0 + 4):
+            for f in range(f0, f0 + 8):
                 ctx.reset_accum()
                 ctx.reset_counters()
                 ctx.render_frames([1000 + f])
                 per_frame.append(ctx.read_sum())
                 rays += ctx.counters()["rays"] if mode == "default" else 0
             imgs[mode] = per_frame
-        for a, b in zip(imgs["default"], imgs["unpruned"]):
-            assert (a.view(np.uint32) == b.view(np.uint32)).all()
-    assert rays > 10_000_000_000
+        for k in range(8):
+            assert (imgs["default"][k].view(np.uint32) == imgs["unpruned"][k].view(np.uint32)).all(), f0 + k
+            assert (imgs["provable"][k].view(np.uint32) == imgs["unpruned"][k].view(np.uint32)).all(), f0 + k
+    assert rays > 40_000_000_000
 
 
 def test_primary_rays_are_never_pruned(ptx, orc, ctx):
