@@ -134,7 +134,7 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
  *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles
  *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned there (pixar_room:
- *                 1.7 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
+ *                 1.6 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
  *                 traversal = 2.
  *   "anyhit"    : 1 (default) = light-visibility rays (is_light_visible, glsl:353-363, and the shadow ray of glsl:439-442)
  *                 stop at the first conclusive blocker instead of finding the closest hit: the shader uses only "is there a
@@ -143,7 +143,7 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 images and reference ray counters; pipeline 2 with pruning only.  0 = every ray is a closest-hit query
  *   "emit_list" : 1 (default) = under "prune" = 1, scenes with at most 32 emissive triangles decide "no emitter can be hit
  *                 nearer" with a bound on each emitter's determinant for the ray at hand instead of the shader's 1e-4 cut-off
- *                 (which on pixar_room switches the any-hit rule off: 133 -> 106 ms per headline frame); 0 = round 2's bound
+ *                 (which on pixar_room switches the any-hit rule off: 133 -> 106 ms per headline frame, 98 with round 3's tighter M); 0 = round 2's bound
  *   "memo"      : 1 = reuse the per-pixel primary hit and the last light-attempt ray for the shadow ray
  *                 (default; both are bit-identical rays in the reference), 0 = trace every ray
  *   "count"     : 1 = also count node visits / triangle tests (slower), 0 = off (default)

@@ -1047,7 +1047,15 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     double diag2 = 0;
     for (int q = 0; q < 3; q++) { centre[q] = 0.5f * bmn[q] + 0.5f * bmx[q]; diag2 += ((double)bmx[q] - bmn[q]) * ((double)bmx[q] - bmn[q]); ctx->bbox_min[q] = bmn[q]; ctx->bbox_max[q] = bmx[q]; }
     const float two_rs = std::nextafter((float)std::sqrt(diag2), INFINITY) * 1.0001f;    // >= 2 x half-diagonal, also after the centre's rounding
-    const float m_cap = 3.0f * two_rs;                                                // rays from within |o - centre|_1 <= 4 Rs are prunable
+    const float rs = 0.5f * two_rs;
+    const float m_cap = 5.001f * rs;                                                  // rays from within |o - centre| <= 4 Rs are prunable (ray_m <= 4.0004 Rs + Rs)
+    float e_max = 0.f;                                                                // the longest triangle edge, rounded up (ray_m)
+    for (uint32_t k = 0; k < T; k++) {
+        const float4 e1 = tris[3 * (size_t)k + 1], e2 = tris[3 * (size_t)k + 2];
+        const double l1 = std::sqrt((double)e1.x * e1.x + (double)e1.y * e1.y + (double)e1.z * e1.z), l2 = std::sqrt((double)e2.x * e2.x + (double)e2.y * e2.y + (double)e2.z * e2.z);
+        const double dx = (double)e2.x - e1.x, dy = (double)e2.y - e1.y, dz = (double)e2.z - e1.z;
+        e_max = std::max(e_max, std::nextafter((float)std::max(std::max(l1, l2), std::sqrt(dx * dx + dy * dy + dz * dz)), INFINITY));
+    }
     // classes: up to PTX_MAX_CLS plane normals, each time the normal of the unclassified triangle with the largest c_o
     // among those that may be class members and gain from it; members = the triangles within delta of +- that normal
     std::vector<TriCoef> slot_coef(T);
@@ -1289,7 +1297,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
         return rc;
     }
     S.N = (int)N; S.T = (int)T; S.L = (int)L;
-    S.center = {centre[0], centre[1], centre[2]}; S.two_rs = two_rs; S.m_cap = m_cap;
+    S.center = {centre[0], centre[1], centre[2]}; S.rs = rs; S.e_max = e_max; S.m_cap = m_cap;
     S.n_cls = n_cls;
     for (int j = 0; j < n_cls; j++) S.cls[j] = cls[j];
     S.n_lbox = n_lbox; S.lcoefs = lcoefs;

@@ -42,7 +42,7 @@ struct DScene {
     uint32_t ref_base;     // byte offset in `nodes` of the reference tree itself (layout 8 behind the octant layouts; 0 when
                            // `nodes` IS the reference tree): rays with an infinite 1/d component walk it (slab_node_ref)
     V3 center;             // centre of the scene's bounding box                         } provable pruning: ray_kappa()
-    float two_rs, m_cap;   // twice its half-diagonal; largest M_ray the coefficients hold for }
+    float rs, e_max, m_cap; // its half-diagonal, the scene's longest triangle edge, the largest M_ray the coefficients hold for }
     int n_cls;             // dominant plane normals of the scene's large flat triangles ("classes", unit vectors)
     V3 cls[PTX_MAX_CLS];
     // any-hit termination of light-visibility rays (pipeline 2; 0 boxes = off): boxes around ALL triangles with a non-zero
@@ -126,7 +126,7 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
 //          rho <= c_c * M_ray * w_ray              for a triangle of a CLASS (its normal within PTX_CLS_DELTA of one of the
 //                                                  scene's n_cls dominant plane normals N_j): there the determinant is
 //                                                  >= 2 * area * (|d . N_j| - delta), so w_ray = max_j 1 / (|d . N_j| - delta)
-//      with c_o, c_c depending only on the triangle's edges and M_ray = |o - centre|_1 + 2 Rs bounding the distances involved.
+//      with c_o, c_c depending only on the triangle's edges and M_ray = max(|o - centre| + Rs, longest edge) bounding the distances involved (ray_m).
 //      A point within rho of a box is inside the box grown by rho, which the ray enters no later than (slab entry of the
 //      box) - rho * max|1/d_k|.  So with kappa = M_ray * max|1/d_k| and kappa2 = kappa * w_ray (ray_kappa, once per ray), a
 //      node whose entry distance tn satisfies
@@ -158,8 +158,14 @@ __device__ __forceinline__ bool prune_far(float tn, float limit, uint32_t packed
     return PRUNE == 2 ? tn > limit : (tn - (coef_other(packed) * kap.k + coef_class(packed) * kap.k2)) > limit;
 }
 // kappa and kappa2 of a ray, a hair above their exact values (v_rcp_f32 is good to 1 ulp); inf when the bound does not apply
+// M of the lemma for a ray from o: any M >= max(|o - v0|, E) over the scene's triangles.  Every vertex lies within Rs of the
+// centre, so |o - v0| <= |o - centre| + Rs; every edge is at most e_max.  (v_sqrt_f32 is good to 1 ulp, the squared length to 4u.)
+__device__ __forceinline__ float ray_m(const DScene& S, V3 o) {
+    const V3 v = o - S.center;
+    return fmaxf(__builtin_amdgcn_sqrtf(dot(v, v)) * 1.0001f + S.rs, S.e_max);
+}
 __device__ __forceinline__ Kappa ray_kappa(const DScene& S, V3 o, V3 d) {
-    const float m = ((fabsf(o.x - S.center.x) + fabsf(o.y - S.center.y)) + fabsf(o.z - S.center.z)) + S.two_rs;
+    const float m = ray_m(S, o);
     const float mind = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
     const float dd = dot(d, d);
     const bool ok = fabsf(dd - 1.0f) <= 1.0e-3f && m <= S.m_cap;          // false for NaN
@@ -202,7 +208,7 @@ __device__ __forceinline__ float light_bound(const DScene& S, V3 o, V3 d, V3 inv
     float slack = PRUNE == 1 ? coef_other(S.lcoefs) * kap.k + coef_class(S.lcoefs) * kap.k2 : 0.0f;
     const bool listed = PRUNE == 1 && S.n_emit != 0u;
     if (listed) {
-        const float M = (((fabsf(o.x - S.center.x) + fabsf(o.y - S.center.y)) + fabsf(o.z - S.center.z)) + S.two_rs) * 1.0001f;
+        const float M = ray_m(S, o) * 1.0001f;
         float rmin = 3.0e38f;
         for (uint32_t k = 0; k < S.n_emit; k++) rmin = fminf(rmin, fabsf(dot(d, mk(S.emit[k]))));
         rmin = rmin - 0.1761f;
