@@ -33,7 +33,8 @@
 #define PTX_POOL_WALK_STEPS 16   // node steps per WALK phase (ends early when the queue could overflow)
 #endif
 #ifndef PTX_POOL_SHADE_W
-#define PTX_POOL_SHADE_W 3       // a lane waiting for SHADE weighs this many QUARTERS of a walking lane / queued leaf in the vote
+#define PTX_POOL_SHADE_W 4       // a lane waiting for SHADE weighs this many QUARTERS of a walking lane / queued leaf in the vote (round 3, with the
+                                 // two-entry blocker cache: 2 / 3 / 4 / 5 / 6 / 8 -> 59.3 / 59.1 / 58.4 / 60.6 / 62.3 / 65.2 ms per headline frame)
 #endif
 
 #ifndef PTX_POOL_WALK_KEEP
@@ -54,6 +55,13 @@
 #ifndef PTX_POOL_CACHE_RESET
 #define PTX_POOL_CACHE_RESET 0   // 0: the blocker cache survives bounces and samples (63.6 -> 62.7 ms per headline frame: the next bounce is
                                  // often shadowed by the same object); a separate entry for bounce 0 (same point for every sample): no gain
+#endif
+#ifndef PTX_POOL_CACHE2
+#define PTX_POOL_CACHE2 1         // the blocker cache keeps the leaves of the last TWO different blockers (scenes with 256 .. 65 534 nodes: two 16-bit node
+                                  // indices in one register).  Counted on the headline: a blocked light ray's blocker sits in the same leaf as the lane's
+                                  // previous blocker in 59 % of the cases, in the last different leaf before that in 24 %, in the third / fourth 7 / 2 %.
+                                  // Both leaves are probed when the ray starts and each one whose box is hit is queued: 10.9 -> 7.5 node visits and
+                                  // 16.2 -> 15.1 triangle tests per traced ray, 60.7 -> 59.1 ms per headline frame (with SHADE_W 4: 58.4)
 #endif
 #ifndef PTX_POOL_MIN_WAVES
 #define PTX_POOL_MIN_WAVES 5      // waves per SIMD the register allocation aims for (caps VGPRs at 96; LDS allows 20 waves per CU)
@@ -102,6 +110,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     // work counters as wave totals in scalar registers: every increment is a ballot + popcount in wave-uniform control flow
     uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
     uint32_t probed = 0xFFFFFFFFu;                   // fc word of the leaf the cache has already queued for the running ray: the walk skips it
+    const bool cache2 = PTX_POOL_CACHE2 && (uint32_t)S.N >= 256u && (uint32_t)S.N < 0xFFFFu;   // (a walk through a tiny tree costs less than the second probe: my_cornell_6 +3 %)
     uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
@@ -142,14 +151,24 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             // blocker cache: before its first step a light ray tests the box of the leaf that blocked the previous attempt and,
             // if hit, queues that leaf (the reference tests it too: its box passes, hence every ancestor's)
             if (PRUNE && __ballot(w0 && (flags & F_PROBE)) != 0ull) {
-                bool probe = false;
-                uint32_t probe_item = 0;
-                float probe_tn = 0.f;
+                bool probe = false, probe2 = false;
+                uint32_t probe_item = 0, probe_item2 = 0;
+                float probe_tn = 0.f, probe_tn2 = 0.f;
                 if (w0 && (flags & F_PROBE)) {
-                    const float4 a = ld16(S.nodes, c_noff), b = ld16(nodes_hi, c_noff);
+                    // two entries (16-bit node indices, newest in the low half): both leaves' records are requested together, and
+                    // each leaf whose box the ray hits is queued
+                    const uint32_t n1 = cache2 ? (c_noff & 0xFFFFu) : c_noff, n2 = cache2 ? (c_noff >> 16) : 0xFFFFu;
+                    const uint32_t o1 = S.ref_base + (n1 << 5), o2 = (cache2 && n2 != 0xFFFFu) ? S.ref_base + (n2 << 5) : o1;
+                    const float4 a = ld16(S.nodes, o1), b = ld16(nodes_hi, o1);
+                    float4 a2 = a, b2 = b;
+                    if (cache2) { a2 = ld16(S.nodes, o2); b2 = ld16(nodes_hi, o2); }
                     probe = slab_node(ro, inv, a, b, probe_tn) && __float_as_int(b.w) >= 0;
                     probe_item = (uint32_t)__float_as_int(b.w) & 0x00FFFFFFu;
-                    if (probe) probed = (uint32_t)__float_as_int(b.w);     // the leaf's fc word (first | count << 24)
+                    if (probe) probed = (uint32_t)__float_as_int(b.w);     // the leaf's fc word (first | count << 24): the walk skips it
+                    if (cache2 && o2 != o1) {                               // (the older leaf may be queued again by the walk: tested twice, same minimum)
+                        probe2 = slab_node(ro, inv, a2, b2, probe_tn2) && __float_as_int(b2.w) >= 0;
+                        probe_item2 = (uint32_t)__float_as_int(b2.w) & 0x00FFFFFFu;
+                    }
                     flags &= ~F_PROBE;
                 }
                 const unsigned long long m = __ballot(probe);     // at most 64 and len < 64 here
@@ -159,6 +178,15 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                     lastpos = pos + 1u;
                 }
                 tail += (uint32_t)__popcll(m);
+                const unsigned long long m2 = __ballot(probe2);
+                if (m2 != 0ull && tail - head + (uint32_t)__popcll(m2) <= (uint32_t)PTX_POOL_QCAP) {   // room for all of them, or none
+                    if (probe2) {
+                        const uint32_t pos = tail + below(m2);
+                        queue[pos & (PTX_POOL_QCAP - 1)] = make_uint2(probe_item2 | (lane << 24), __float_as_uint(probe_tn2));
+                        lastpos = pos + 1u;
+                    }
+                    tail += (uint32_t)__popcll(m2);
+                }
             }
             // ordered = every walking lane may take the entry-first shortcut (octant layouts, finite 1/d): wave-uniform
             const bool ordered = S.oct_stride != 0u && __ballot(w0 && (flags & F_INF)) == 0ull;
@@ -334,7 +362,9 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                             // a light-visibility ray stopped by a triangle without emission: shade_step needs no index (tri < 0);
                             // the blocker's leaf is remembered for the next attempt instead
                             tri = -1;
-                            c_noff = S.ref_base + ((uint32_t)__float_as_int(ld16(S.tris, slot * 48u + 32u).w) << 5);
+                            const uint32_t nn = (uint32_t)__float_as_int(ld16(S.tris, slot * 48u + 32u).w);   // reference-tree node of the blocker's leaf
+                            if (!cache2) c_noff = nn;
+                            else if (nn != (c_noff & 0xFFFFu)) c_noff = (c_noff << 16) | nn;
                         } else {
                             tri = __float_as_int(ld16(S.tris, slot * 48u).w);
                         }
