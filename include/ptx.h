@@ -134,7 +134,7 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
  *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles
  *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned there (pixar_room:
- *                 1.6 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
+ *                 1.7 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
  *                 traversal = 2.
  *   "anyhit"    : 1 (default) = light-visibility rays (is_light_visible, glsl:353-363, and the shadow ray of glsl:439-442)
  *                 stop at the first conclusive blocker instead of finding the closest hit: the shader uses only "is there a
