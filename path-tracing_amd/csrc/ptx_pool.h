@@ -111,7 +111,8 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
     uint32_t w_rays = 0, w_traced = 0, w_hits = 0, w_att = 0, w_pf = 0;
     uint32_t probed = 0xFFFFFFFFu;                   // fc word of the leaf the cache has already queued for the running ray: the walk skips it
     const bool cache2 = PTX_POOL_CACHE2 && (uint32_t)S.N >= 256u && (uint32_t)S.N < 0xFFFFu;   // (a walk through a tiny tree costs less than the second probe: my_cornell_6 +3 %)
-    uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: byte offset (from S.nodes) of the reference-tree record of the last blocker's leaf
+    uint32_t c_noff = 0xFFFFFFFFu;                   // blocker cache: reference-tree node index of the last blocker's leaf; with cache2 two of them, 16 bits
+                                                     // each (low half = newest, 0xFFFF = none)
     uint32_t lastpos = 0;                            // queue position after the lane's newest item: all of the ray's items have
                                                      // been tested once head has passed it (items are consumed in order)
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 // any-hit rule for light-visibility rays: a TRI phase found a conclusive blocker (distance bits 0, below)
                 if (tb == 0.0f) { i = 0xFFFFFFFFu; w0 = false; }
             }
-            // blocker cache: before its first step a light ray tests the box of the leaf that blocked the previous attempt and,
+            // blocker cache: before its first step a light ray tests the boxes of the leaves that blocked the lane's previous attempts and,
             // if hit, queues that leaf (the reference tests it too: its box passes, hence every ancestor's)
             if (PRUNE && __ballot(w0 && (flags & F_PROBE)) != 0ull) {
                 bool probe = false, probe2 = false;
