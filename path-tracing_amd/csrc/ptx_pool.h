@@ -17,11 +17,12 @@
 // dequeue and ends its walk at the next WALK phase.  The key carries the emission flag of its triangle in bit 0
 // (t bits << 32 | slot << 1 | flag: still ordered by (t, slot)).
 // Blocker cache: 92 % of the light attempts are blocked and the next attempt of the same bounce (same origin, a direction a few
-// degrees off) is blocked by the same triangle in every second case.  A lane remembers the leaf of its last blocker (the node
-// record's byte offset, looked up by slot in the triangle record); when its next attempt starts, the leaf's box is tested at
-// once and, if hit, the leaf goes into the queue before the walk has taken a step (the reference tests that leaf too: its
-// box passes, hence every ancestor's).  A conclusive hit in the next TRI phase ends the ray after at most one WALK phase
-// (forcing a TRI phase right after such a SHADE phase was measured: no gain).
+// degrees off) is blocked in the same leaf in 59 % of the cases, in the lane's last different blocker leaf before that in 24 %.
+// A lane remembers the leaves of its last two different blockers (reference-tree node indices, looked up by slot in the
+// triangle record; one entry for trees under 256 or over 65 534 nodes); when its next attempt starts, both leaves' boxes are
+// tested at once and every one that is hit goes into the queue before the walk has taken a step (the reference tests such a
+// leaf too: its box passes, hence every ancestor's).  A conclusive hit in the next TRI phase ends the ray after at most one
+// WALK phase (forcing a TRI phase right after such a SHADE phase was measured: no gain).
 #pragma once
 #include "ptx_wave.h"
 #include <type_traits>
