@@ -135,6 +135,17 @@ def trace_closest(s, o, d):
     return t, tri, cnt.as_dict()
 
 
+def trace_pixel(s, p, timestamp, px, py, cap=1 << 16):
+    """One pixel of one frame and the rays it traces: (rgb, o (n,3), d (n,3), t (n,), tri (n,)).  Diagnostic."""
+    log = np.zeros((cap, 8), dtype=np.float32)
+    rgb = np.zeros(3, dtype=np.float32)
+    cs, cp = c_scene(s), c_params(p)
+    lib().orc_trace_pixel.restype = C.c_uint32
+    n = lib().orc_trace_pixel(C.byref(cs), C.byref(cp), C.c_int32(int(timestamp)), C.c_uint32(px), C.c_uint32(py), _fp(rgb), _fp(log), C.c_uint32(cap))
+    n = min(int(n), cap)
+    return rgb, log[:n, 0:3].copy(), log[:n, 3:6].copy(), log[:n, 6].copy(), log[:n, 7].copy().view(np.int32)
+
+
 def primary_hits(s, p):
     t = np.zeros((p.height, p.width), dtype=np.float32)
     tri = np.zeros((p.height, p.width), dtype=np.int32)

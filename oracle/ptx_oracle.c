@@ -216,9 +216,26 @@ static int bvh_closest_experimental(const orc_scene *s, v3 o, v3 d, float *out_t
     return 0;
 }
 
-/* glsl:207-249.  Returns hit flag; *tri = original triangle index of the closest hit. */
+/* diagnostic ray log of orc_trace_pixel (one thread): 8 words per traced ray -- o, d, t, tri (int bits) */
+static __thread float *g_ray_log = 0;
+static __thread uint32_t g_ray_log_cap = 0, g_ray_log_n = 0;
+static int bvh_closest_literal(const orc_scene *s, v3 o, v3 d, float *out_t, int32_t *out_tri, orc_counters *c);
+
 static int bvh_closest(const orc_scene *s, v3 o, v3 d, float *out_t, int32_t *out_tri, orc_counters *c) {
-    if (g_traversal_mode) return bvh_closest_experimental(s, o, d, out_t, out_tri, c);
+    int hit = g_traversal_mode ? bvh_closest_experimental(s, o, d, out_t, out_tri, c) : bvh_closest_literal(s, o, d, out_t, out_tri, c);
+    if (g_ray_log) {
+        if (g_ray_log_n < g_ray_log_cap) {
+            float *r = g_ray_log + 8 * (size_t)g_ray_log_n;
+            r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = *out_t;
+            memcpy(r + 7, out_tri, 4);
+        }
+        g_ray_log_n++;
+    }
+    return hit;
+}
+
+/* glsl:207-249.  Returns hit flag; *tri = original triangle index of the closest hit. */
+static int bvh_closest_literal(const orc_scene *s, v3 o, v3 d, float *out_t, int32_t *out_tri, orc_counters *c) {
     float best = 1.0e38f;
     int32_t best_tri = -1;
     int32_t i = 0;
@@ -429,6 +446,26 @@ int orc_max_threads(void) {
 #else
     return 1;
 #endif
+}
+
+/* one pixel of one frame (glsl:493-529), with every ray it traces written to ray_log (8 words each: o, d, t, tri);
+ * returns the number of rays traced (may exceed cap: then only the first cap were stored).  Diagnostic. */
+uint32_t orc_trace_pixel(const orc_scene *s, const orc_params *p, int32_t timestamp, uint32_t px, uint32_t py,
+                         float rgb_out[3], float *ray_log, uint32_t cap) {
+    float d[3];
+    uint32_t seed[2];
+    orc_counters local;
+    memset(&local, 0, sizeof local);
+    g_ray_log = ray_log; g_ray_log_cap = cap; g_ray_log_n = 0;
+    orc_primary_dir(p, px, py, d);
+    orc_seed_init(px, py, timestamp, seed);
+    v3 sum = V(0, 0, 0);
+    for (int sidx = 0; sidx != p->sample_count; ++sidx)
+        sum = add(sum, ray_radiance(s, p, ld3(p->cam_src), ld3(d), seed, &local));
+    sum = dvs(sum, (float)p->sample_count);
+    rgb_out[0] = clamp01(sum.x); rgb_out[1] = clamp01(sum.y); rgb_out[2] = clamp01(sum.z);
+    g_ray_log = 0;
+    return g_ray_log_n;
 }
 
 void orc_render_frame(const orc_scene *s, const orc_params *p, int32_t timestamp, uint32_t y0,

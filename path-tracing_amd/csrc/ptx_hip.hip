@@ -353,6 +353,7 @@ struct ptx_ctx {
     const float4* d_emit_list = nullptr;                       // provable any-hit rule: (e2 x e1) / n per emissive triangle (at most PTX_MAX_EMIT; ptx_kernels.h light_bound)
     uint32_t n_emit_list = 0;
     float emit_c1 = 0.f;
+    int opt_margin_lat = PTX_MARGIN_LAT_PPM;                   // option "margin_lat": the margin rule's lateral allowance in ppm of the scene's diagonal (0 = round 2's rule)
     int opt_emit_list = 1;                                     // option "emit_list": 0 = the provable rule bounds the emitters by their largest coefficients only (round 2)
     uint32_t n_big_slots = 0;
 
@@ -422,6 +423,7 @@ static inline float __uint_as_float_host(uint32_t u) { float f; std::memcpy(&f, 
 static inline DScene scene_view(const ptx_ctx* c) {
     DScene S = c->S;
     if ((c->opt_traversal & 2) && c->nodes_sah) { S.nodes = c->nodes_sah; S.N = c->N_sah; S.oct_stride = (uint32_t)c->N_sah * 32u; S.ref_base = 8u * S.oct_stride; }
+    S.lat = (float)c->opt_margin_lat * 1.0e-6f * (2.0f * c->S.rs);   // margin rule: lateral allowance per unit of max|1/d_k| (ptx_kernels.h)
     if (!c->opt_anyhit) S.n_lbox = 0;              // (kernels without pruning never look at the boxes)
     // provable rule: with emitters whose position-error coefficient is this large the bound never lets a ray stop (pixar_room's
     // lamp: c_o = 0.054, slack = c_o * kappa of several scene units), and computing it would only cost time
@@ -1391,6 +1393,7 @@ extern "C" int ptx_set_option(ptx_ctx* ctx, const char* key, int64_t value) {
     else if (k == "overlap" && (value == 0 || value == 1)) ctx->opt_overlap = (int)value;
     else if (k == "anyhit" && (value == 0 || value == 1)) ctx->opt_anyhit = (int)value;
     else if (k == "emit_list" && (value == 0 || value == 1)) ctx->opt_emit_list = (int)value;
+    else if (k == "margin_lat" && value >= 0 && value <= 1000000) ctx->opt_margin_lat = (int)value;
     else if (k == "memo" && (value == 0 || value == 1)) ctx->opt_memo = (int)value;
     else if (k == "count" && (value == 0 || value == 1)) ctx->opt_count = (int)value;
     else if (k == "pipeline" && (value >= 0 && value <= 2)) ctx->opt_pipeline = (int)value;

@@ -42,6 +42,7 @@ struct DScene {
     uint32_t ref_base;     // byte offset in `nodes` of the reference tree itself (layout 8 behind the octant layouts; 0 when
                            // `nodes` IS the reference tree): rays with an infinite 1/d component walk it (slab_node_ref)
     V3 center;             // centre of the scene's bounding box                         } provable pruning: ray_kappa()
+    float lat;              // margin rule: lateral allowance, option "margin_lat" (ppm) x the scene's diagonal (ray_lat)
     float rs, e_max, m_cap; // its half-diagonal, the scene's longest triangle edge, the largest M_ray the coefficients hold for }
     int n_cls;             // dominant plane normals of the scene's large flat triangles ("classes", unit vectors)
     V3 cls[PTX_MAX_CLS];
@@ -135,16 +136,26 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
 //      largest coefficients beneath the node (every triangle counts in exactly one of the two): inner nodes carry them in
 //      fc (see the layout above), leaves in their first triangle / pair record.  Rays with an infinite 1/d component, rays
 //      that are not unit length and rays from far outside the scene get kappa = inf and are never pruned.
-//   2  heuristic margin  tn > best * (1 + 1e-3) + 1e-3  (option "prune" = 2, the library default): faster, but NOT exact for
-//      every conceivable ray -- rays that graze a large triangle can lose it (ptx_selfcheck_pruning constructs such rays; none
-//      occurs in the frames compared so far, include/ptx.h "prune").
+//   2  heuristic margin  tn > best * (1 + 1e-3) + 1e-3 + lat  (option "prune" = 2, the library default): faster, but NOT proven
+//      for every conceivable ray (include/ptx.h "prune").
 #define PTX_PRUNE_REL 0.001f
 #define PTX_PRUNE_ABS 0.001f
+// lat, round 3.  The shader's triangle test accepts grazing hits (determinant near its 1e-4 cut-off) whose point lies BESIDE the
+// triangle -- 3e-5 .. 2e-4 scene units beside a lamp panel of pixar_room (1e-5 of the scene's diagonal) in the six pixel-frames of
+// 2.1e9 that round 2's margin got wrong on C5's whole job (tools/whole_job_check.py, tools/dbg/find_diff.py) -- and a ray with a
+// small direction component enters the triangle's box later by that distance times max|1/d_k|: 0.017 .. 0.055 in those rays,
+// against a margin of 0.004 .. 0.009.  So the margin grows by lat = margin_lat x scene diagonal x max|1/d_k| (ray_lat; a ray with
+// a component below 1e-3 is hardly pruned at all).  Option "margin_lat" in ppm of the diagonal, default 3000 = 300 x the largest
+// distance seen: ptx_selfcheck_pruning's adversarial rays, which break round 2's rule (0 ppm) 1 700 times in 5e8, find nothing
+// from 3000 ppm on (100 / 300 / 1000 ppm: 16 / 12 / 2, all on teapot); headline 58.7 -> 59.7 ms per frame (100 ppm: 58.9).
+// Still a heuristic: the proven bound on that distance is c_o * M_ray (PRUNE = 1).
+#define PTX_MARGIN_LAT_PPM 3000
 #define PTX_PRUNE_SAFE_REL 1.52587890625e-05f   // 2^-16: covers the three roundings of a computed slab entry distance
 
+// lat (margin rule only): the ray's lateral allowance in units of t, ray_lat below
 template <int PRUNE>
-__device__ __forceinline__ float prune_limit(float best) {
-    return PRUNE == 2 ? best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS : best * (1.0f + PTX_PRUNE_SAFE_REL);
+__device__ __forceinline__ float prune_limit(float best, float lat = 0.0f) {
+    return PRUNE == 2 ? best * (1.0f + PTX_PRUNE_REL) + PTX_PRUNE_ABS + lat : best * (1.0f + PTX_PRUNE_SAFE_REL);
 }
 // the two coefficients of a node, packed by the host (pack_coefs): [sign][c_o: 8-bit exponent, 7-bit mantissa][c_c: 0, 8, 7],
 // both rounded up
@@ -184,6 +195,11 @@ __device__ __forceinline__ uint32_t pack_kappa(Kappa k) {
     return (ha << 16) | (hb & 0xFFFFu);
 }
 __device__ __forceinline__ Kappa unpack_kappa(uint32_t w) { Kappa k; k.k = __uint_as_float(w & 0xFFFF0000u); k.k2 = __uint_as_float(w << 16); return k; }
+
+// margin rule: lateral allowance of a ray with reciprocal direction inv (inf or NaN: the ray is never pruned)
+__device__ __forceinline__ float ray_lat(const DScene& S, V3 inv) { return S.lat * fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z)); }
+// the same from the direction (pipeline 2's TRI lanes hold the owner's d, not 1/d): v_rcp_f32 of the smallest component
+__device__ __forceinline__ float ray_lat_d(const DScene& S, V3 d) { return S.lat * __builtin_amdgcn_rcpf(fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z))); }
 
 // Light-visibility rays (glsl:353-363, 439-442) consume only "is there a hit" and the emission of the closest one.  A hit on
 // a triangle WITHOUT emission settles both -- hit, not visible -- as soon as no emissive triangle can be hit nearer; the
@@ -264,6 +280,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
     uint32_t i = 0;                       // -1 (end) wraps to 0xFFFFFFFF >= N
     const uint32_t N = (uint32_t)S.N;
     float limit = 3.0e38f;
+    const float lat = PRUNE == 2 ? ray_lat(S, inv) : 0.0f;
     const bool deg = inv_degenerate(inv);
     const uint32_t nbase = deg ? S.ref_base : octant(d) * S.oct_stride;
     do {
@@ -317,7 +334,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
                 best = t;
                 best_k = k;
                 best_tri = __float_as_int(v0.w);
-                if (PRUNE) limit = prune_limit<PRUNE>(best);
+                if (PRUNE) limit = prune_limit<PRUNE>(best, lat);
             }
             k++;
         }
@@ -344,6 +361,7 @@ __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, f
     const bool deg = inv_degenerate(inv);
     const bool ordered = S.oct_stride != 0u && !deg;
     float best = 1.0e38f, limit = 3.0e38f;
+    const float lat = PRUNE == 2 ? ray_lat(S, inv) : 0.0f;
     uint32_t best_k = 0xFFFFFFFFu;
     uint32_t i = 0;
     const uint32_t N = (uint32_t)S.N;
@@ -375,7 +393,7 @@ __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, f
             if (rem <= 2) break;
             k += 2u; pbyte += 80u;
         }
-        if (PRUNE) limit = prune_limit<PRUNE>(best);
+        if (PRUNE) limit = prune_limit<PRUNE>(best, lat);
     }
     out_t = best;
     out_tri = best < 1.0e38f ? __float_as_int(ld16(S.tris, best_k * 48u).w) : -1;

@@ -57,6 +57,9 @@
 #define PTX_POOL_CACHE_RESET 0   // 0: the blocker cache survives bounces and samples (63.6 -> 62.7 ms per headline frame: the next bounce is
                                  // often shadowed by the same object); a separate entry for bounce 0 (same point for every sample): no gain
 #endif
+#ifndef PTX_POOL_CACHE
+#define PTX_POOL_CACHE 1          // 0: no blocker cache (diagnostic builds)
+#endif
 #ifndef PTX_POOL_CACHE2
 #define PTX_POOL_CACHE2 1         // the blocker cache keeps the leaves of the last TWO different blockers (scenes with 256 .. 65 534 nodes: two 16-bit node
                                   // indices in one register).  Counted on the headline: a blocked light ray's blocker sits in the same leaf as the lane's
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
             if (PRUNE) {
                 const unsigned long long key = keys[lane];
                 const float tb = __uint_as_float((uint32_t)(key >> 32));
-                limit = prune_limit<PRUNE>(tb);
+                limit = prune_limit<PRUNE>(tb, PRUNE == 2 ? ray_lat(S, inv) : 0.0f);
                 // any-hit rule for light-visibility rays: a TRI phase found a conclusive blocker (distance bits 0, below)
                 if (tb == 0.0f) { i = 0xFFFFFFFFu; w0 = false; }
             }
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 const float b = __uint_as_float((uint32_t)(keys[owner] >> 32));
                 Kappa ok = {0.f, 0.f};
                 if (PRUNE == 1) ok = unpack_kappa(kap[owner]);
-                go = go && !prune_far<PRUNE>(__uint_as_float(it.y), prune_limit<PRUNE>(b), __float_as_uint(r4.w), ok);   // r4.w: the leaf's packed coefficients
+                go = go && !prune_far<PRUNE>(__uint_as_float(it.y), prune_limit<PRUNE>(b, PRUNE == 2 ? ray_lat_d(S, d) : 0.0f), __float_as_uint(r4.w), ok);   // r4.w: the leaf's packed coefficients
             }
             float bt = 1.0e38f;
             uint32_t bk = 0xFFFFFFFFu;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
 #endif
                 if (PRUNE && S.n_lbox != 0u) {               // glsl:353-363 / 439-442: only "hit" and the closest hit's emission are used
                     tlm[lane] = (lightray && !deg) ? light_bound<PRUNE>(S, ro, rd, inv, unpack_kappa(pk)) : -3.0e38f;
-                    if (lightray && !deg && c_noff != 0xFFFFFFFFu) flags |= F_PROBE;   // blocker cache: tested when the walk starts
+                    if (PTX_POOL_CACHE && lightray && !deg && c_noff != 0xFFFFFFFFu) flags |= F_PROBE;   // blocker cache: tested when the walk starts
                 }
             }
             w_traced += (uint32_t)__popcll(__ballot(start_trav));

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                             best = t;
                             best_k = k + u;
                             best_tri = __float_as_int(tv0[u].w);
-                            if (PRUNE) limit = prune_limit<PRUNE>(best);
+                            if (PRUNE) limit = prune_limit<PRUNE>(best, PRUNE == 2 ? ray_lat(S, inv) : 0.0f);
                         }
                     }
                 }

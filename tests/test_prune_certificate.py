@@ -6,12 +6,16 @@ Three statements, each with its test (DESIGN.md "Pruning and exactness"):
     and traces each with and without pruning, >= 1e8 rays per BASELINE scene over eight families (grazing hits on large
     triangles, rays skimming bounding-box faces, rays in a triangle's own plane, (nearly) axis-parallel rays, rays towards
     vertices and edges, ...): (t bits, triangle id) agree for every one; so do whole frames through every pipeline.
-  * the default margin rule (option "prune" = 2) is NOT exact for every conceivable ray and the same generator shows it: family
-    3 (grazing a large triangle from afar) finds rays whose closest hit it loses -- kept as a known-answer test of the
-    checker and as the measure of the caveat include/ptx.h states.
-  * on the rays a render really traces the default rule has never changed a bit: the whole headline job (64 frames, 44 G rays) is
-    compared here between the default and the unpruned walk, every pixel of every frame bit for bit (one frame of every
-    BASELINE configuration in tests/test_gpu_parity.py::test_full_size_properties); and primary rays are never pruned at all."""
+  * the default margin rule (option "prune" = 2) has no proof.  Round 2's form of it (option "margin_lat" = 0) is NOT exact: the
+    same generator finds rays whose closest hit it loses (family 3, grazing a large triangle from afar, and on bedroom2_v5 most
+    other families) -- kept as a known-answer test of the checker -- and so did a render: C5's whole job (256 frames of 3840 x 2160,
+    12 bounces, 726 G rays, tools/whole_job_check.py) came out with six pixel-frames of 2.1e9 different from the unpruned walk, all
+    of them rays that skim the lower edge of one lamp panel of pixar_room with a direction component below 4e-3.  Round 3's form
+    (lateral allowance, ptx_kernels.h PTX_MARGIN_LAT_PPM) gets those six frames right and leaves the generator nothing to find in
+    1e8 rays per scene; both are tested here.
+  * the whole headline job (64 frames, 44 G rays) is compared here between the default, the provable and the unpruned walk, every
+    pixel of every frame bit for bit (the whole jobs of the other BASELINE configurations: profiles/r03_whole_job_check.json; one
+    frame of each in tests/test_gpu_parity.py::test_full_size_properties); and primary rays are never pruned at all."""
 import numpy as np
 import pytest
 
@@ -29,7 +33,7 @@ def describe(r):
 @pytest.fixture
 def ctx(gpu_ctx):
     yield gpu_ctx
-    for k, v in dict(pipeline=2, traversal=3, prune=2, count=0).items():      # the library defaults
+    for k, v in dict(pipeline=2, traversal=3, prune=2, count=0, margin_lat=3000).items():      # the library defaults
         gpu_ctx.set_option(k, v)
 
 
@@ -148,18 +152,56 @@ def test_primary_rays_are_never_pruned(ptx, orc, ctx):
         assert (tri == tri_o).all() and (t.view(np.uint32) == t_o.view(np.uint32)).all()
 
 
-def test_heuristic_margin_is_not_exact_and_the_checker_sees_it(ptx, ctx):
-    """prune = 2 (the default) loses grazing hits on large triangles: the generator must find some (else the zeros above mean
-    nothing), and they must stay as rare as include/ptx.h says."""
+def test_round_2_margin_is_not_exact_and_the_checker_sees_it(ptx, ctx):
+    """margin_lat = 0 (round 2's rule) loses grazing hits on large triangles: the generator must find some (else the zeros above
+    and below mean nothing), and they stay rare even among adversarial rays."""
     found = 0
     for name in ("teapot", "pixar_room", "bedroom2_v5"):
         ctx.upload_scene(ptx.load_scene(name))
-        ctx.set_option("traversal", 3)
-        ctx.set_option("prune", 2)
+        for k, v in dict(traversal=3, prune=2, margin_lat=0).items():
+            ctx.set_option(k, v)
         r = ctx.selfcheck_pruning(3, RAYS_PER_FAMILY, seed=20263)
         found += r["mismatches"]
-        assert r["mismatches"] < r["rays"] // 10_000          # rare even among adversarial rays
+        assert r["mismatches"] < r["rays"] // 5_000
     assert found > 0
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_default_margin_with_lateral_allowance_leaves_the_generator_nothing(ptx, ctx, name):
+    """The default rule (margin_lat = 3000 ppm of the scene's diagonal per unit of max|1/d_k|): 0 differing rays in 1e8 adversarial
+    rays per scene, the same rays that break round 2's rule.  Not a proof (prune = 1 has one) -- the measure of what is left."""
+    ctx.upload_scene(ptx.load_scene(name))
+    for k, v in dict(pipeline=2, traversal=3, prune=2).items():
+        ctx.set_option(k, v)
+    for fam in FAMILIES:
+        r = ctx.selfcheck_pruning(fam, RAYS_PER_FAMILY, seed=20260 + fam)
+        assert r["mismatches"] == 0, f"{name} family {fam}: {r['mismatches']} of {r['rays']} rays differ\n" + describe(r)
+
+
+def test_c5_frames_that_round_2s_margin_got_wrong(ptx, ctx):
+    """Known answers from a real job: frames 52, 107, 125, 162, 168, 170 of C5 (pixar_room 3840 x 2160, 12 bounces) each have ONE pixel
+    where round 2's margin rule and the unpruned walk differ -- a light ray towards the lower edge of a lamp panel, |d_y| < 4e-3,
+    accepted by the shader's triangle test 3e-5 .. 2e-4 beside the neighbouring triangle, whose leaf box the ray enters 0.017 .. 0.055
+    later (tools/dbg/find_diff.py).  The default rule renders all six like the unpruned walk; with margin_lat = 0 the two frames
+    whose ray fails in every pipeline still show the difference (frame 52's depends on the order the leaves are tested in)."""
+    c = ptx.CONFIGS["C5"]
+    ctx.upload_scene(ptx.load_scene(c["scene"]))
+    ctx.set_params(ptx.config_params(c["scene"], c["width"], c["height"], c["sample_count"], c["max_path_length"]))
+    ctx.set_option("pipeline", 2)
+
+    def frame(f, **opts):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.reset_accum()
+        ctx.render_frames([1000 + f], first_frame_number=f)
+        return np.ascontiguousarray(ctx.read_sum()).view(np.uint32)
+
+    for f, pixel in ((52, None), (107, (2075, 183)), (125, None), (162, None), (168, None), (170, (1408, 522))):
+        want = frame(f, traversal=2, prune=2, margin_lat=3000)
+        assert (frame(f, traversal=3, prune=2, margin_lat=3000) == want).all(), f
+        if pixel is not None:
+            bad = np.argwhere((frame(f, traversal=3, prune=2, margin_lat=0) != want).any(axis=2))
+            assert bad.tolist() == [list(pixel)], (f, bad.tolist())
 
 
 def test_provable_anyhit_with_the_emitter_list(ptx, orc, ctx):

@@ -1,0 +1,74 @@
+"""Whole BASELINE jobs, frame by frame: the default walk (leaf-SAH tree, margin rule, any-hit light rays) against the unpruned
+walk of the same tree (option traversal = 2), every pixel of every frame bit for bit.  The headline job is a test
+(tests/test_prune_certificate.py); this tool does the same for any configuration -- C5 alone is 256 frames of 3840 x 2160 at 12
+bounces, too long for the suite -- and writes what it found to gpurun_out/whole_job_check_<config>.json (copied to profiles/).
+
+    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402  (one HIP runtime per process)
+import numpy as np  # noqa: E402
+import ptx_import  # noqa: E402
+
+
+def main():
+    m = ptx_import.load()
+    args = sys.argv[1:]
+    limit = None
+    if "--frames" in args:
+        k = args.index("--frames")
+        limit = int(args[k + 1])
+        del args[k:k + 2]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    rc = 0
+    for cfg in args or ["headline"]:
+        c = m.CONFIGS[cfg]
+        n = c["frames"] if limit is None else min(limit, c["frames"])
+        ctx = m.Context(0)
+        ctx.upload_scene(m.load_scene(c["scene"]))
+        ctx.set_params(m.config_params(c["scene"], c["width"], c["height"], c["sample_count"], c["max_path_length"]))
+        ctx.set_option("pipeline", 2)
+        rays = samples = 0
+        differing = []
+        ms = {"default": 0.0, "unpruned": 0.0}
+        t_start = time.time()
+        for f in range(n):
+            img = {}
+            for mode, opts in (("default", dict(traversal=3, prune=2)), ("unpruned", dict(traversal=2, prune=2))):
+                for k, v in opts.items():
+                    ctx.set_option(k, v)
+                ctx.reset_accum()
+                ctx.reset_counters()
+                t0 = time.time()
+                ctx.render_frames([1000 + f], first_frame_number=f)
+                ctx.synchronize()
+                ms[mode] += (time.time() - t0) * 1e3
+                img[mode] = np.ascontiguousarray(ctx.read_sum()).view(np.uint32)
+                if mode == "default":
+                    cn = ctx.counters()
+                    rays += cn["rays"]
+                    samples += cn["samples"]
+            bad = int((img["default"] != img["unpruned"]).sum())
+            if bad:
+                differing.append({"frame": f, "words": bad})
+                rc = 1
+            if f % 8 == 7 or f == n - 1:
+                print(f"{cfg}: {f + 1}/{n} frames, {rays / 1e9:.1f} G rays, {len(differing)} differing, {time.time() - t_start:.0f} s", flush=True)
+        out = {"config": cfg, "scene": c["scene"], "width": c["width"], "height": c["height"], "bounces": c["max_path_length"],
+               "frames_compared": n, "frames_of_job": c["frames"], "samples": samples, "reference_rays": rays,
+               "differing_frames": differing, "ms_per_frame_one_frame_per_call": {k: round(v / n, 2) for k, v in ms.items()},
+               "compared": "default (traversal=3, prune=2, anyhit=1) vs unpruned walk (traversal=2): accumulation buffer bits of every frame"}
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}.json"), "w"), indent=1)
+        print(json.dumps(out), flush=True)
+        ctx.close()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())
