@@ -123,19 +123,25 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 2 = leaf-SAH tree, 3 = both (default)
  *   "prune"     : the pruning rule of traversal bit 0 for BOUNCE rays (primary rays are always traced unpruned, so the
  *                 primary hit of every pixel is the reference's closest hit unconditionally).
- *                 2 (default) = margin rule: a node is skipped when its box is entered beyond 1.001 * best + 0.001.  Every
- *                 frame rendered with it so far equals the unpruned reference bit for bit (all fixtures, whole 1080p / 4K
- *                 frames of every BASELINE scene), but it is NOT exact for every conceivable ray: the shader's triangle test
- *                 becomes ill-conditioned for a hit that grazes a large triangle within ~1e-3 rad, and if such a hit's
- *                 computed t falls below the true box entry by more than the margin while another hit lies in between, the
- *                 pruned walk returns that other hit.  ptx_selfcheck_pruning constructs such rays (a few per 10^7
- *                 adversarial ones; none occur in the renders compared).
+ *                 2 (default) = margin rule: a node is skipped when its box is entered beyond
+ *                 1.001 * best + 0.001 + lat, lat = margin_lat x scene diagonal x max|1/d_k| of the ray (below).  Faster, NOT
+ *                 proven.  What it guards against: the shader's triangle test is ill-conditioned for a hit that grazes a
+ *                 triangle (determinant near its 1e-4 cut-off); it then accepts points beside the triangle, whose leaf box
+ *                 the ray enters later than the computed t -- by that distance times max|1/d_k| -- and if another hit lies in
+ *                 between, the pruned walk returns that other hit.  Round 2's form of the rule (lat = 0) did get six pixels
+ *                 of C5's whole job wrong that way (256 frames of 3840 x 2160, 726 G rays; tools/whole_job_check.py), and
+ *                 ptx_selfcheck_pruning's adversarial rays break it ~20 times per 1e7.  With the default lat every frame of
+ *                 every BASELINE job equals the unpruned walk bit for bit (profiles/r03_whole_job_check.json) and the
+ *                 adversarial generator finds nothing in 1e8 rays per BASELINE scene.
  *                 1 = provable rule: a node is skipped only when a rounding-error bound of the shader's own triangle test
  *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
  *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles
  *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned there (pixar_room:
  *                 1.7 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
  *                 traversal = 2.
+ *   "margin_lat": the margin rule's lateral allowance in ppm of the scene's diagonal (0 .. 1000000; default 3000, i.e. 300 x
+ *                 the largest distance beside a triangle seen in the failures above; 0 = round 2's rule).  Headline cost of
+ *                 the default against 0: 58.7 -> 59.7 ms per frame.  Ignored by "prune" = 1.
  *   "anyhit"    : 1 (default) = light-visibility rays (is_light_visible, glsl:353-363, and the shadow ray of glsl:439-442)
  *                 stop at the first conclusive blocker instead of finding the closest hit: the shader uses only "is there a
  *                 hit" and the closest hit's emission, and a hit on a triangle of emission (0,0,0) that no emissive triangle
@@ -226,8 +232,8 @@ int ptx_trace_closest(ptx_ctx *ctx, const float *o, const float *d, uint32_t n, 
  * axis-parallel, 7 towards vertices and edges), traces each one with and without pruning through the tree the "traversal"
  * option selects (bit 1) with the arithmetic of the selected pipeline, and reports how many (t bits, triangle) results
  * differ, with the first 16 offenders (o.xyz, d.xyz, t exact, t pruned; triangle exact, triangle pruned).
- * tests/test_prune_certificate.py runs >= 1e8 rays per BASELINE scene: zero differences under prune = 1; under prune = 2
- * family 3 finds the grazing rays described at option "prune". */
+ * tests/test_prune_certificate.py runs >= 1e8 rays per BASELINE scene: zero differences under prune = 1 and under the default
+ * prune = 2; with margin_lat = 0 (round 2's margin rule) family 3 finds the grazing rays described at option "prune". */
 typedef struct ptx_selfcheck_result {
     uint64_t rays, hits, mismatches;
     float first[16][8];

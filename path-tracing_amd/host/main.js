@@ -17,8 +17,9 @@
  *   goes to device f mod N over the full image, the devices render side by side, and the per-device float buffers are
  *   summed by one RCCL all-reduce when the image (or a checkpoint) is read -- the reference's frame loop (main.js:391-438)
  *   for a whole node.  The same device listed N times rehearses that path on one GPU (summed by a kernel, no RCCL).
- * --prune: rule for skipping BVH nodes behind the best hit (include/ptx.h): 2 = margin rule (default, fastest; equal to the
- *   unpruned walk on every rendered frame tested, but not proven), 1 = rule with a proof (DESIGN.md section 4).
+ * --prune: rule for skipping BVH nodes behind the best hit (include/ptx.h): 2 = margin rule with lateral allowance (default,
+ *   fastest; equal to the unpruned walk on every frame of every BASELINE job, but not proven), 1 = rule with a proof
+ *   (DESIGN.md section 4).
  * --checkpoint: progressive rendering like renderAsync (main.js:391-436): frames are rendered in batches of
  *   --checkpoint-every; after each batch {sum buffer, frames done} is written to the file (atomically, via rename).  If
  *   the file exists when the program starts, rendering resumes after the frames it holds (same size required); the
