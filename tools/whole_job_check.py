@@ -3,7 +3,8 @@ walk of the same tree (option traversal = 2), every pixel of every frame bit for
 (tests/test_prune_certificate.py); this tool does the same for any configuration -- C5 alone is 256 frames of 3840 x 2160 at 12
 bounces, too long for the suite -- and writes what it found to gpurun_out/whole_job_check_<config>.json (copied to profiles/).
 
-    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N]
+    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N] [--mode default|provable|margin0]
+(--mode provable: option prune = 1 against the unpruned walk; margin0: round 2's margin rule, option margin_lat = 0)
 """
 import json
 import os
@@ -25,6 +26,13 @@ def main():
         k = args.index("--frames")
         limit = int(args[k + 1])
         del args[k:k + 2]
+    mode_name = "default"
+    if "--mode" in args:
+        k = args.index("--mode")
+        mode_name = args[k + 1]
+        del args[k:k + 2]
+    mode_opts = {"default": dict(traversal=3, prune=2, margin_lat=3000), "provable": dict(traversal=3, prune=1, margin_lat=3000),
+                 "margin0": dict(traversal=3, prune=2, margin_lat=0)}[mode_name]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     rc = 0
     for cfg in args or ["headline"]:
@@ -40,7 +48,7 @@ def main():
         t_start = time.time()
         for f in range(n):
             img = {}
-            for mode, opts in (("default", dict(traversal=3, prune=2)), ("unpruned", dict(traversal=2, prune=2))):
+            for mode, opts in (("default", mode_opts), ("unpruned", dict(traversal=2, prune=2))):
                 for k, v in opts.items():
                     ctx.set_option(k, v)
                 ctx.reset_accum()
@@ -63,8 +71,9 @@ def main():
         out = {"config": cfg, "scene": c["scene"], "width": c["width"], "height": c["height"], "bounces": c["max_path_length"],
                "frames_compared": n, "frames_of_job": c["frames"], "samples": samples, "reference_rays": rays,
                "differing_frames": differing, "ms_per_frame_one_frame_per_call": {k: round(v / n, 2) for k, v in ms.items()},
-               "compared": "default (traversal=3, prune=2, anyhit=1) vs unpruned walk (traversal=2): accumulation buffer bits of every frame"}
-        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}.json"), "w"), indent=1)
+               "mode": mode_name, "options": mode_opts,
+               "compared": f"{mode_name} {mode_opts} (anyhit=1) vs unpruned walk (traversal=2): accumulation buffer bits of every frame"}
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}{'' if mode_name == 'default' else '_' + mode_name}.json"), "w"), indent=1)
         print(json.dumps(out), flush=True)
         ctx.close()
     return rc
