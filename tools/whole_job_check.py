@@ -3,7 +3,7 @@ walk of the same tree (option traversal = 2), every pixel of every frame bit for
 (tests/test_prune_certificate.py); this tool does the same for any configuration -- C5 alone is 256 frames of 3840 x 2160 at 12
 bounces, too long for the suite -- and writes what it found to gpurun_out/whole_job_check_<config>.json (copied to profiles/).
 
-    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N] [--mode default|provable|margin0]
+    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N] [--first-frame F] [--mode default|provable|margin0]
 (--mode provable: option prune = 1 against the unpruned walk; margin0: round 2's margin rule, option margin_lat = 0)
 """
 import json
@@ -26,6 +26,11 @@ def main():
         k = args.index("--frames")
         limit = int(args[k + 1])
         del args[k:k + 2]
+    first = 0
+    if "--first-frame" in args:                      # other timestamps than the job's own: frames first .. first + n - 1
+        k = args.index("--first-frame")
+        first = int(args[k + 1])
+        del args[k:k + 2]
     mode_name = "default"
     if "--mode" in args:
         k = args.index("--mode")
@@ -46,7 +51,7 @@ def main():
         differing = []
         ms = {"default": 0.0, "unpruned": 0.0}
         t_start = time.time()
-        for f in range(n):
+        for f in range(first, first + n):
             img = {}
             for mode, opts in (("default", mode_opts), ("unpruned", dict(traversal=2, prune=2))):
                 for k, v in opts.items():
@@ -66,14 +71,14 @@ def main():
             if bad:
                 differing.append({"frame": f, "words": bad})
                 rc = 1
-            if f % 8 == 7 or f == n - 1:
-                print(f"{cfg}: {f + 1}/{n} frames, {rays / 1e9:.1f} G rays, {len(differing)} differing, {time.time() - t_start:.0f} s", flush=True)
+            if f % 8 == 7 or f == first + n - 1:
+                print(f"{cfg}: {f + 1 - first}/{n} frames, {rays / 1e9:.1f} G rays, {len(differing)} differing, {time.time() - t_start:.0f} s", flush=True)
         out = {"config": cfg, "scene": c["scene"], "width": c["width"], "height": c["height"], "bounces": c["max_path_length"],
-               "frames_compared": n, "frames_of_job": c["frames"], "samples": samples, "reference_rays": rays,
+               "frames_compared": n, "first_frame": first, "frames_of_job": c["frames"], "samples": samples, "reference_rays": rays,
                "differing_frames": differing, "ms_per_frame_one_frame_per_call": {k: round(v / n, 2) for k, v in ms.items()},
                "mode": mode_name, "options": mode_opts,
                "compared": f"{mode_name} {mode_opts} (anyhit=1) vs unpruned walk (traversal=2): accumulation buffer bits of every frame"}
-        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}{'' if mode_name == 'default' else '_' + mode_name}.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}{'' if mode_name == 'default' else '_' + mode_name}{'' if first == 0 else '_from' + str(first)}.json"), "w"), indent=1)
         print(json.dumps(out), flush=True)
         ctx.close()
     return rc
