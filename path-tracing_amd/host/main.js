@@ -11,7 +11,7 @@
  *
  *   node main.js --scene file.gltf|file.obj|file.ptxs [--camera preset | --camera-json file] [--width 256]
  *        [--height 256] [--frames 5] [--spp 5] [--bounces 5] [--out image.png|.ppm] [--dump-sum file.f32]
- *        [--device 0 | --gpus N | --devices 0,1,...] [--traversal 0..3] [--prune 1|2] [--save-scene out.ptxs] [--light-material name]
+ *        [--device 0 | --gpus N | --devices 0,1,...] [--traversal 0..3] [--prune 1|2] [--margin-lat ppm] [--save-scene out.ptxs] [--light-material name]
  *        [--checkpoint file.ptxc] [--checkpoint-every 16] [--compat-out image.png [--compat-rules 1|2] [--compat-gamma 0|1]]
  * --gpus N (devices 0 .. N-1) or --devices a,b,...: one PathTracer over several GPUs.  Frame f of every renderFrames call
  *   goes to device f mod N over the full image, the devices render side by side, and the per-device float buffers are
@@ -78,6 +78,7 @@ function main() {
   pt.setParams(a.width, a.height, camera, a.bounces, a.spp);
   if (a.traversal !== undefined) pt.setOption('traversal', a.traversal);
   if (a.prune !== undefined) pt.setOption('prune', a.prune);
+  if (a.marginLat !== undefined) pt.setOption('margin_lat', a.marginLat);
   if (a.compatOut) {
     if (a.checkpoint) throw new Error('--compat-out cannot be combined with --checkpoint (the 8-bit target is not checkpointed)');
     const rules = a.compatRules === undefined ? 1 : a.compatRules;
