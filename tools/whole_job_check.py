@@ -3,7 +3,7 @@ walk of the same tree (option traversal = 2), every pixel of every frame bit for
 (tests/test_prune_certificate.py); this tool does the same for any configuration -- C5 alone is 256 frames of 3840 x 2160 at 12
 bounces, too long for the suite -- and writes what it found to gpurun_out/whole_job_check_<config>.json (copied to profiles/).
 
-    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N] [--first-frame F] [--mode default|provable|margin0]
+    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N] [--first-frame F] [--mode default|provable|margin0|unpruned] [--ref-literal]
 (--mode provable: option prune = 1 against the unpruned walk; margin0: round 2's margin rule, option margin_lat = 0)
 """
 import json
@@ -31,13 +31,18 @@ def main():
         k = args.index("--first-frame")
         first = int(args[k + 1])
         del args[k:k + 2]
+    ref_opts, ref_name = dict(traversal=2, prune=2), "unpruned walk of the leaf-SAH tree (traversal=2)"
+    if "--ref-literal" in args:                      # reference = the shader's literal walk of the reference tree (traversal = 0, pipeline 0)
+        args.remove("--ref-literal")
+        ref_opts, ref_name = dict(traversal=0, prune=2, pipeline=0), "literal threaded walk of the reference tree (traversal=0, pipeline 0)"
     mode_name = "default"
     if "--mode" in args:
         k = args.index("--mode")
         mode_name = args[k + 1]
         del args[k:k + 2]
     mode_opts = {"default": dict(traversal=3, prune=2, margin_lat=3000), "provable": dict(traversal=3, prune=1, margin_lat=3000),
-                 "margin0": dict(traversal=3, prune=2, margin_lat=0)}[mode_name]
+                 "margin0": dict(traversal=3, prune=2, margin_lat=0),
+                 "unpruned": dict(traversal=2, prune=2, margin_lat=3000)}[mode_name]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     rc = 0
     for cfg in args or ["headline"]:
@@ -53,7 +58,8 @@ def main():
         t_start = time.time()
         for f in range(first, first + n):
             img = {}
-            for mode, opts in (("default", mode_opts), ("unpruned", dict(traversal=2, prune=2))):
+            for mode, opts in (("default", mode_opts), ("unpruned", ref_opts)):
+                ctx.set_option("pipeline", 2)
                 for k, v in opts.items():
                     ctx.set_option(k, v)
                 ctx.reset_accum()
@@ -77,8 +83,8 @@ def main():
                "frames_compared": n, "first_frame": first, "frames_of_job": c["frames"], "samples": samples, "reference_rays": rays,
                "differing_frames": differing, "ms_per_frame_one_frame_per_call": {k: round(v / n, 2) for k, v in ms.items()},
                "mode": mode_name, "options": mode_opts,
-               "compared": f"{mode_name} {mode_opts} (anyhit=1) vs unpruned walk (traversal=2): accumulation buffer bits of every frame"}
-        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}{'' if mode_name == 'default' else '_' + mode_name}{'' if first == 0 else '_from' + str(first)}.json"), "w"), indent=1)
+               "compared": f"{mode_name} {mode_opts} (anyhit=1) vs {ref_name}: accumulation buffer bits of every frame"}
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}{'' if mode_name == 'default' else '_' + mode_name}{'' if first == 0 else '_from' + str(first)}{'_vs_literal' if 'literal' in ref_name else ''}.json"), "w"), indent=1)
         print(json.dumps(out), flush=True)
         ctx.close()
     return rc
