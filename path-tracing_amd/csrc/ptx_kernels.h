@@ -243,7 +243,8 @@ __device__ __forceinline__ float light_bound(const DScene& S, V3 o, V3 d, V3 inv
     }
     return listed ? tl - slack : tl;      // the listed slack is already in the distance (light_settles)
 }
-// does a blocker at distance tb settle a light-visibility ray whose light_bound is tl?
+// does a blocker at distance tb settle a light-visibility ray whose light_bound is tl?  (Margin rule: without the lateral allowance
+// of prune_limit -- the emitter boxes are padded sideways instead, by 5e-4 of the scene's diagonal, ptx_hip.hip "lbox".)
 template <int PRUNE>
 __device__ __forceinline__ bool light_settles(const DScene& S, float tl, float tb, Kappa kap) {
     if (PRUNE == 1 && S.n_emit != 0u) return tl > prune_limit<1>(tb);     // false for NaN and -inf
