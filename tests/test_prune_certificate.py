@@ -228,3 +228,21 @@ def test_provable_anyhit_with_the_emitter_list(ptx, orc, ctx):
         visits[emit_list] = c["node_visits"]
     ctx.set_option("emit_list", 1)
     assert visits[1] < 0.8 * visits[0], visits
+
+
+def test_whole_job_checker_on_the_smallest_job(ptx, ctx, monkeypatch, tmp_path):
+    """tools/whole_job_check.py (the tool behind profiles/r03_whole_job_check.json) on C1, the one-frame cornell job: runs, finds no
+    differing frame under any mode, against either reference."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("whole_job_check", os.path.join(root, "tools", "whole_job_check.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    for extra in ([], ["--mode", "provable"], ["--mode", "unpruned", "--ref-literal"]):
+        monkeypatch.setattr(sys, "argv", ["whole_job_check.py", "C1"] + extra)
+        assert tool.main() == 0
+    out = json.load(open(os.path.join(root, "gpurun_out", "whole_job_check_C1.json")))
+    assert out["frames_compared"] == 1 and out["differing_frames"] == [] and out["reference_rays"] > 5_000_000
