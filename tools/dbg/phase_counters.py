@@ -8,6 +8,8 @@ m = ptx_import.load()
 c = m.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "headline"]
 s = m.load_scene(c["scene"]); p = m.config_params(c["scene"], c["width"], c["height"], c["sample_count"], c["max_path_length"])
 ctx = m.Context(0); ctx.upload_scene(s); ctx.set_params(p)
+for kv in filter(None, os.environ.get("PTX_OPTS", "").split(",")):      # e.g. PTX_OPTS=prune=1,emit_list=0
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for pipeline in (2,):
     ctx.set_option("pipeline", pipeline)
     for count in (0, 1):
