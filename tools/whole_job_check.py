@@ -54,6 +54,7 @@ def main():
         ctx.set_option("pipeline", 2)
         rays = samples = 0
         differing = []
+        running = None                                   # float32 sum of the per-frame images of the mode under test, in frame order
         ms = {"default": 0.0, "unpruned": 0.0}
         t_start = time.time()
         for f in range(first, first + n):
@@ -73,13 +74,27 @@ def main():
                     cn = ctx.counters()
                     rays += cn["rays"]
                     samples += cn["samples"]
+            running = img["default"].view(np.float32).copy() if running is None else running + img["default"].view(np.float32)
             bad = int((img["default"] != img["unpruned"]).sum())
             if bad:
                 differing.append({"frame": f, "words": bad})
                 rc = 1
             if f % 8 == 7 or f == first + n - 1:
                 print(f"{cfg}: {f + 1 - first}/{n} frames, {rays / 1e9:.1f} G rays, {len(differing)} differing, {time.time() - t_start:.0f} s", flush=True)
-        out = {"config": cfg, "scene": c["scene"], "width": c["width"], "height": c["height"], "bounces": c["max_path_length"],
+        # the same frames in launches of up to 64 (tile-major task list, frames summed by k_accumulate in frame order): the
+        # accumulation buffer must equal the float32 sum of the single-frame images above, bit for bit
+        for k, v in mode_opts.items():
+            ctx.set_option(k, v)
+        ctx.reset_accum()
+        t0 = time.time()
+        ctx.render_frames([1000 + f for f in range(first, first + n)], first_frame_number=first)
+        ctx.synchronize()
+        batched_ms = (time.time() - t0) * 1e3 / n
+        batched = np.ascontiguousarray(ctx.read_sum()).view(np.uint32)
+        batched_bad = int((batched != running.view(np.uint32)).sum())
+        rc = rc or (1 if batched_bad else 0)
+        print(f"{cfg}: {n} frames in one call: {batched_ms:.2f} ms per frame, {batched_bad} words differ from the sum of the single frames", flush=True)
+        out = {"config": cfg, "one_call_of_all_frames": {"ms_per_frame": round(batched_ms, 2), "words_differing_from_sum_of_single_frames": batched_bad}, "scene": c["scene"], "width": c["width"], "height": c["height"], "bounces": c["max_path_length"],
                "frames_compared": n, "first_frame": first, "frames_of_job": c["frames"], "samples": samples, "reference_rays": rays,
                "differing_frames": differing, "ms_per_frame_one_frame_per_call": {k: round(v / n, 2) for k, v in ms.items()},
                "mode": mode_name, "options": mode_opts,
