@@ -246,3 +246,11 @@ def test_whole_job_checker_on_the_smallest_job(ptx, ctx, monkeypatch, tmp_path):
         assert tool.main() == 0
     out = json.load(open(os.path.join(root, "gpurun_out", "whole_job_check_C1.json")))
     assert out["frames_compared"] == 1 and out["differing_frames"] == [] and out["reference_rays"] > 5_000_000
+
+
+def test_margin_lat_option_range(ptx, ctx):
+    for bad in (-1, 1_000_001):
+        with pytest.raises(ptx.PtxError):
+            ctx.set_option("margin_lat", bad)
+    ctx.set_option("margin_lat", 0)
+    ctx.set_option("margin_lat", 1_000_000)
