@@ -137,7 +137,7 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
  *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles
  *                 that are large against the shader's absolute 1e-4 determinant cut-off that little is pruned there (pixar_room:
- *                 1.7 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
+ *                 1.66 x the time of rule 2; the other BASELINE scenes: 1.11 - 1.18 x).  Callers that need the guarantee use it or
  *                 traversal = 2.
  *   "margin_lat": the margin rule's lateral allowance in ppm of the scene's diagonal (0 .. 1000000; default 3000, i.e. 300 x
  *                 the largest distance beside a triangle seen in the failures above; 0 = round 2's rule).  Headline cost of

@@ -1283,6 +1283,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
             emit_list.push_back(make_float4((float)(gx / n), (float)(gy / n), (float)(gz / n), 0.f));
         }
     }
+    while (!emit_list.empty() && emit_list.size() % 4 != 0) emit_list.push_back(emit_list.back());   // light_bound reads four at a time (a repeated entry changes no minimum)
     const float emit_c1 = emit_list.empty() ? 0.f : std::nextafter((float)(0.672 / e_min), INFINITY);
     ctx->n_emit_list = (uint32_t)emit_list.size();
     ctx->emit_c1 = emit_c1;
@@ -1301,7 +1302,7 @@ extern "C" int ptx_upload_scene(ptx_ctx* ctx, const ptx_scene* sc) {
     S.N = (int)N; S.T = (int)T; S.L = (int)L;
     S.center = {centre[0], centre[1], centre[2]}; S.rs = rs; S.e_max = e_max; S.m_cap = m_cap;
     S.n_cls = n_cls;
-    for (int j = 0; j < n_cls; j++) S.cls[j] = cls[j];
+    for (int j = 0; j < PTX_MAX_CLS; j++) S.cls[j] = cls[j < n_cls ? j : 0];      // ray_kappa takes the minimum over all PTX_MAX_CLS entries
     S.n_lbox = n_lbox; S.lcoefs = lcoefs;
     std::memcpy(S.lbox, lbox, sizeof(lbox));
     ctx->nodes_sah = nullptr; ctx->N_sah = 0;
