@@ -3,7 +3,7 @@ walk of the same tree (option traversal = 2), every pixel of every frame bit for
 (tests/test_prune_certificate.py); this tool does the same for any configuration -- C5 alone is 256 frames of 3840 x 2160 at 12
 bounces, too long for the suite -- and writes what it found to gpurun_out/whole_job_check_<config>.json (copied to profiles/).
 
-    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N] [--first-frame F] [--mode default|provable|margin0|unpruned] [--ref-literal]
+    python tools/whole_job_check.py C2 C3 C4 C5 [--frames N] [--first-frame F] [--mode default|provable|margin0|unpruned] [--pipeline 0|1|2] [--ref-literal]
 (--mode provable: option prune = 1 against the unpruned walk; margin0: round 2's margin rule, option margin_lat = 0)
 """
 import json
@@ -35,6 +35,11 @@ def main():
     if "--ref-literal" in args:                      # reference = the shader's literal walk of the reference tree (traversal = 0, pipeline 0)
         args.remove("--ref-literal")
         ref_opts, ref_name = dict(traversal=0, prune=2, pipeline=0), "literal threaded walk of the reference tree (traversal=0, pipeline 0)"
+    pipeline = 2
+    if "--pipeline" in args:                         # the kernel of the mode under test (the reference stays as chosen above)
+        k = args.index("--pipeline")
+        pipeline = int(args[k + 1])
+        del args[k:k + 2]
     mode_name = "default"
     if "--mode" in args:
         k = args.index("--mode")
@@ -43,6 +48,7 @@ def main():
     mode_opts = {"default": dict(traversal=3, prune=2, margin_lat=3000), "provable": dict(traversal=3, prune=1, margin_lat=3000),
                  "margin0": dict(traversal=3, prune=2, margin_lat=0),
                  "unpruned": dict(traversal=2, prune=2, margin_lat=3000)}[mode_name]
+    mode_opts = dict(mode_opts, pipeline=pipeline)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     rc = 0
     for cfg in args or ["headline"]:
@@ -83,6 +89,7 @@ def main():
                 print(f"{cfg}: {f + 1 - first}/{n} frames, {rays / 1e9:.1f} G rays, {len(differing)} differing, {time.time() - t_start:.0f} s", flush=True)
         # the same frames in launches of up to 64 (tile-major task list, frames summed by k_accumulate in frame order): the
         # accumulation buffer must equal the float32 sum of the single-frame images above, bit for bit
+        ctx.set_option("pipeline", 2)
         for k, v in mode_opts.items():
             ctx.set_option(k, v)
         ctx.reset_accum()
@@ -99,7 +106,7 @@ def main():
                "differing_frames": differing, "ms_per_frame_one_frame_per_call": {k: round(v / n, 2) for k, v in ms.items()},
                "mode": mode_name, "options": mode_opts,
                "compared": f"{mode_name} {mode_opts} (anyhit=1) vs {ref_name}: accumulation buffer bits of every frame"}
-        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}{'' if mode_name == 'default' else '_' + mode_name}{'' if first == 0 else '_from' + str(first)}{'_vs_literal' if 'literal' in ref_name else ''}.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"whole_job_check_{cfg}{'' if mode_name == 'default' else '_' + mode_name}{'' if first == 0 else '_from' + str(first)}{'_vs_literal' if 'literal' in ref_name else ''}{'' if pipeline == 2 else '_pipeline' + str(pipeline)}.json"), "w"), indent=1)
         print(json.dumps(out), flush=True)
         ctx.close()
     return rc
