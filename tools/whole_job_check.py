@@ -53,7 +53,7 @@ def main():
     rc = 0
     for cfg in args or ["headline"]:
         c = m.CONFIGS[cfg]
-        n = c["frames"] if limit is None else min(limit, c["frames"])
+        n = c["frames"] if limit is None else limit          # more than the job has: further timestamps (1000 + frame)
         ctx = m.Context(0)
         ctx.upload_scene(m.load_scene(c["scene"]))
         ctx.set_params(m.config_params(c["scene"], c["width"], c["height"], c["sample_count"], c["max_path_length"]))
