@@ -132,7 +132,8 @@ int ptx_set_params(ptx_ctx *ctx, const ptx_params *params);
  *                 of C5's whole job wrong that way (256 frames of 3840 x 2160, 726 G rays; tools/whole_job_check.py), and
  *                 ptx_selfcheck_pruning's adversarial rays break it ~20 times per 1e7.  With the default lat every frame of
  *                 every BASELINE job equals the unpruned walk bit for bit (profiles/r03_whole_job_check.json) and the
- *                 adversarial generator finds nothing in 1e8 rays per BASELINE scene.
+ *                 adversarial generator finds nothing in 1e8 rays per BASELINE scene (in 1e10: 8 rays on teapot, fired at a
+ *                 grazing angle of 2^-24 rad from hundreds of units outside the scene; none on the other scenes).
  *                 1 = provable rule: a node is skipped only when a rounding-error bound of the shader's own triangle test
  *                 shows that no triangle beneath it can yield a computed t below the best one (DESIGN.md "Pruning and
  *                 exactness"): identical to the unpruned reference for EVERY ray, but the bound is so wide for triangles

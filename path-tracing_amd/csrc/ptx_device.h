@@ -152,7 +152,10 @@ __device__ __forceinline__ bool slab_node(V3 o, V3 inv, float4 a, float4 b, floa
 // follows SwiftShader, where min(a, b) = a < b ? a : b and max(a, b) = a > b ? a : b (a NaN operand yields b; probed with
 // the derived debug shader).  A NaN in the y slab then hides the x and y slabs, one in the z slab rejects the box: the
 // result depends on the reference's own hierarchy, so these rays walk the reference tree (DScene::ref_base).  tNear is NaN
-// (then the box is a miss) or the entry distance of the slabs that were not hidden: a lower bound, so best-t pruning stays valid.
+// (then the box is a miss), the entry distance of the slabs that were not hidden (a lower bound), or -- a ray with TWO infinite
+// components that starts in two bounding planes at once -- +inf with tFar = +inf as well, which the shader counts as a hit
+// (inf <= inf): such a box must never be pruned, so the margin rule's limit is +inf for these rays (ray_lat = inf) and before the
+// first hit (round 3; 3e38 until then, which lost one hit in 1.25e9 axis-parallel rays of ptx_selfcheck_pruning's family 6).
 __device__ __forceinline__ float min_2nd(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float max_2nd(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ bool slab_node_ref(V3 o, V3 inv, float4 a, float4 b, float& tNear) {

@@ -286,7 +286,7 @@ __device__ __forceinline__ bool closest_hit(const DScene& S, V3 o, V3 d, float& 
     uint32_t best_k = 0xFFFFFFFFu;        // inorder slot of the winner: ties on t go to the smaller slot (reference order)
     uint32_t i = 0;                       // -1 (end) wraps to 0xFFFFFFFF >= N
     const uint32_t N = (uint32_t)S.N;
-    float limit = 3.0e38f;
+    float limit = __builtin_inff();       // no hit yet: nothing is out of reach (a box the reference enters "at +inf", below, included)
     const float lat = PRUNE == 2 ? ray_lat(S, inv) : 0.0f;
     const bool deg = inv_degenerate(inv);
     const uint32_t nbase = deg ? S.ref_base : octant(d) * S.oct_stride;
@@ -367,7 +367,7 @@ __device__ __forceinline__ bool closest_hit_pairs(const DScene& S, V3 o, V3 d, f
     if (PRUNE == 1) kappa = ray_kappa(S, o, d);
     const bool deg = inv_degenerate(inv);
     const bool ordered = S.oct_stride != 0u && !deg;
-    float best = 1.0e38f, limit = 3.0e38f;
+    float best = 1.0e38f, limit = __builtin_inff();
     const float lat = PRUNE == 2 ? ray_lat(S, inv) : 0.0f;
     uint32_t best_k = 0xFFFFFFFFu;
     uint32_t i = 0;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
 
     int flags = F_ALIVE;
     V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f), inv = mk(0.f, 0.f, 0.f);
-    float limit = 3.0e38f;
+    float limit = __builtin_inff();
     if (PRUNE) tlm[lane] = -3.0e38f;
     uint32_t i = 0xFFFFFFFFu, nbase = 0;
     const uint32_t N = (uint32_t)S.N;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64, PTX_POOL_MIN_WAVES) void k_render_pool(DScene S
                 keys[lane] = PTX_POOL_KEY_NONE;
                 uint32_t pk = 0u;
                 if (PRUNE == 1) { pk = pack_kappa(ray_kappa(S, ro, rd)); kap[lane] = pk; }
-                limit = 3.0e38f;
+                limit = __builtin_inff();
                 i = 0;
                 lastpos = head;
                 // rays with an infinite or NaN 1/d component walk the reference tree with the selecting slab test (slab_node_ref)

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
     // registers carried through the loop: lane flags, the ray, the traversal cursor
     int flags = F_ALIVE;
     V3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f), inv = mk(0.f, 0.f, 0.f);
-    float best = 1.0e38f, limit = 3.0e38f;
+    float best = 1.0e38f, limit = __builtin_inff();
     Kappa kappa = {0.f, 0.f};
     int best_tri = -1;
     uint32_t best_k = 0xFFFFFFFFu;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64, PTX_WAVE_MIN_WAVES) void k_render_wave(DScene S
                 const bool deg = inv_degenerate(inv);
                 flags = deg ? (flags | F_INF) : (flags & ~F_INF);
                 nbase = deg ? S.ref_base : octant(rd) * S.oct_stride;
-                best = 1.0e38f; limit = 3.0e38f; best_tri = -1; best_k = 0xFFFFFFFFu;
+                best = 1.0e38f; limit = __builtin_inff(); best_tri = -1; best_k = 0xFFFFFFFFu;
                 if (PRUNE == 1) kappa = ray_kappa(S, ro, rd);
                 i = 0; nq = 0; k = 0; kend = 0;
                 flags |= F_TRAV;

@@ -254,3 +254,30 @@ def test_margin_lat_option_range(ptx, ctx):
             ctx.set_option("margin_lat", bad)
     ctx.set_option("margin_lat", 0)
     ctx.set_option("margin_lat", 1_000_000)
+
+
+def test_axis_parallel_ray_that_starts_in_two_bounding_planes(ptx, orc, ctx):
+    """Known answer found by 1e10 adversarial rays (round 3): d = (-1, 0, 0) from a point that lies in a y plane AND a z plane of
+    the boxes above its target.  0 * inf = NaN in two slabs makes the shader's slab test report tNear = tFar = +inf, a hit; a best-t
+    limit of 3e38 "before the first hit" cut that box and the walk returned a hit 2.4 farther.  Every mode and pipeline must give the
+    literal walk's answer (a +inf limit until there is a hit, and always for rays with an infinite 1/d component)."""
+    s = ptx.load_scene("bedroom2_v5")
+    ctx.upload_scene(s)
+    o = np.array([[-2.4672701358795166, -2.413858413696289, 5.96727180480957]], dtype=np.float32)
+    d = np.array([[-1.0, 0.0, 0.0]], dtype=np.float32)
+    t_o, tri_o, _ = orc.trace_closest(s, o, d)
+    assert int(tri_o[0]) == 1979 and abs(float(t_o[0]) - 2.0480468) < 1e-6
+    for pipeline in (0, 1, 2):
+        for opts in (dict(traversal=3, prune=2), dict(traversal=3, prune=2, margin_lat=0), dict(traversal=1, prune=2), dict(traversal=3, prune=1),
+                     dict(traversal=2, prune=2), dict(traversal=0, prune=2)):
+            ctx.set_option("margin_lat", 3000)
+            ctx.set_option("pipeline", pipeline)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            t, tri = ctx.trace_closest(o, d)
+            assert int(tri[0]) == int(tri_o[0]) and t.view(np.uint32)[0] == t_o.view(np.uint32)[0], (pipeline, opts, float(t[0]), int(tri[0]))
+    # the generator's family of axis-parallel rays at the size that found it
+    for k, v in dict(pipeline=2, traversal=3, prune=2, margin_lat=3000).items():
+        ctx.set_option(k, v)
+    r = ctx.selfcheck_pruning(6, 1_250_000_000, seed=777006)
+    assert r["mismatches"] == 0, describe(r)
