@@ -147,7 +147,8 @@ __device__ __forceinline__ void flush_counters(const LocalCnt& c, unsigned long 
 // against a margin of 0.004 .. 0.009.  So the margin grows by lat = margin_lat x scene diagonal x max|1/d_k| (ray_lat; a ray with
 // a component below 1e-3 is hardly pruned at all).  Option "margin_lat" in ppm of the diagonal, default 3000 = 300 x the largest
 // distance seen: ptx_selfcheck_pruning's adversarial rays, which break round 2's rule (0 ppm) 1 700 times in 5e8, find nothing
-// from 3000 ppm on (100 / 300 / 1000 ppm: 16 / 12 / 2, all on teapot); headline 58.7 -> 59.7 ms per frame (100 ppm: 58.9).
+// from 3000 ppm on in 5e8 (100 / 300 / 1000 ppm: 16 / 12 / 2, all on teapot; in 7.5e10: 3 .. 8 per 1.25e9 on teapot, rays fired from
+// hundreds of units outside the scene, none elsewhere); headline 58.7 -> 59.7 ms per frame (100 ppm: 58.9).
 // Still a heuristic: the proven bound on that distance is c_o * M_ray (PRUNE = 1).
 #define PTX_MARGIN_LAT_PPM 3000
 #define PTX_PRUNE_SAFE_REL 1.52587890625e-05f   // 2^-16: covers the three roundings of a computed slab entry distance
