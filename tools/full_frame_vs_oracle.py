@@ -1,7 +1,7 @@
 """One WHOLE frame of a BASELINE configuration, every pixel: the HIP path (library defaults) against the CPU oracle, bit for bit, and
 the reference ray counters.  The suite compares row samples at full size (the oracle needs about a second of 16 cores per million
 samples); this tool does the whole frame once and writes gpurun_out/full_frame_vs_oracle_<config>_frame<F>.json.
-    python tools/full_frame_vs_oracle.py headline C4 C3 C2 [C5] [--frame F]
+    python tools/full_frame_vs_oracle.py headline C4 C3 C2 [C5] [--frame F] [--size W H]
 The oracle is the checker here, as in tests/ -- nothing under path-tracing_amd/ uses it."""
 import json
 import os
@@ -24,10 +24,17 @@ def main():
         k = args.index("--frame")
         frame = int(args[k + 1])
         del args[k:k + 2]
+    size = None
+    if "--size" in args:                                       # another image size than the configuration's (aspect < 1, edge tiles)
+        k = args.index("--size")
+        size = (int(args[k + 1]), int(args[k + 2]))
+        del args[k:k + 3]
     rc = 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for cfg in args or ["headline"]:
-        c = m.CONFIGS[cfg]
+        c = dict(m.CONFIGS[cfg])
+        if size:
+            c["width"], c["height"] = size
         s = m.load_scene(c["scene"])
         p = m.config_params(c["scene"], c["width"], c["height"], c["sample_count"], c["max_path_length"])
         ctx = m.Context(0)
@@ -56,7 +63,7 @@ def main():
                "counters": {k: int(oc[k]) for k in ("samples", "rays", "ray_hits", "light_attempts")},
                "oracle_seconds": round(dt, 1), "oracle_threads": threads}
         print(json.dumps(out), flush=True)
-        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"full_frame_vs_oracle_{cfg}_frame{frame}.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"full_frame_vs_oracle_{cfg}_{c['width']}x{c['height']}_frame{frame}.json"), "w"), indent=1)
         rc = rc or (1 if bad or not same_counts else 0)
         ctx.close()
     return rc
