@@ -29,6 +29,11 @@ def main():
         k = args.index("--size")
         size = (int(args[k + 1]), int(args[k + 2]))
         del args[k:k + 3]
+    modes = [""]
+    if "--modes" in args:                                      # further option sets for the HIP side, e.g. "memo=0;pipeline=1;prune=1,anyhit=0"
+        k = args.index("--modes")
+        modes += [x for x in args[k + 1].split(";") if x]
+        del args[k:k + 2]
     rc = 0
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     for cfg in args or ["headline"]:
@@ -40,10 +45,18 @@ def main():
         ctx = m.Context(0)
         ctx.upload_scene(s)
         ctx.set_params(p)
-        ctx.reset_accum(); ctx.reset_counters()
-        ctx.render_frames([1000 + frame], first_frame_number=frame)
-        got = np.ascontiguousarray(ctx.read_sum())
-        gc = ctx.counters()
+        renders = {}
+        defaults = dict(pipeline=2, traversal=3, prune=2, anyhit=1, memo=1, overlap=1, margin_lat=3000)
+        for mode in modes:
+            for k, v in defaults.items():
+                ctx.set_option(k, v)
+            for kv in filter(None, mode.split(",")):
+                ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+            ctx.reset_accum(); ctx.reset_counters()
+            ctx.render_frames([1000 + frame], first_frame_number=frame)
+            renders[mode or "defaults"] = (np.ascontiguousarray(ctx.read_sum()).copy(), ctx.counters())
+            print(f"{cfg} frame {frame}: rendered with [{mode or 'defaults'}]", flush=True)
+        got, gc = renders["defaults"]
         t0 = time.time()
         threads = min(16, orc.max_threads())
         want = np.zeros((p.height, p.width, 3), dtype=np.float32)
@@ -58,7 +71,12 @@ def main():
         dt = time.time() - t0
         bad = int((got.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum())
         same_counts = all(gc[k] == oc[k] for k in ("samples", "rays", "ray_hits", "light_attempts"))
-        out = {"config": cfg, "scene": c["scene"], "width": c["width"], "height": c["height"], "bounces": c["max_path_length"], "frame": frame,
+        other = {}
+        for mode, (img, cn) in renders.items():
+            other[mode] = {"differing_pixels": int((img.view(np.uint32) != want.view(np.uint32)).any(axis=2).sum()),
+                           "reference_counters_equal": all(cn[k] == oc[k] for k in ("samples", "rays", "ray_hits", "light_attempts"))}
+            rc = rc or (1 if other[mode]["differing_pixels"] or not other[mode]["reference_counters_equal"] else 0)
+        out = {"config": cfg, "option_sets": other, "scene": c["scene"], "width": c["width"], "height": c["height"], "bounces": c["max_path_length"], "frame": frame,
                "pixels": c["width"] * c["height"], "differing_pixels": bad, "reference_counters_equal": same_counts,
                "counters": {k: int(oc[k]) for k in ("samples", "rays", "ray_hits", "light_attempts")},
                "oracle_seconds": round(dt, 1), "oracle_threads": threads}
