@@ -41,6 +41,21 @@ def test_primary_dirs_and_hits_bit_exact(gpu_ctx, ptx, orc, name, size, traversa
     assert (bits(t_g) == bits(t_o)).all()
 
 
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C3", "C4", "headline", "C5"])
+def test_primary_hits_of_every_configuration_at_full_size(gpu_ctx, ptx, orc, cfg):
+    """north_star's first bar where it counts: triangle id and t bits of EVERY pixel of every BASELINE configuration (up to
+    3840 x 2160) against the oracle's literal walk, under every traversal option and both pruning rules (tools/full_size_primary_hits.py)."""
+    c = ptx.CONFIGS[cfg]
+    s, p = setup(gpu_ctx, ptx, c["scene"], c["width"], c["height"])
+    t_o, tri_o, _ = orc.primary_hits(s, p)
+    for traversal, prune in ((3, 2), (3, 1), (2, 2), (1, 2), (0, 2)):
+        gpu_ctx.set_option("traversal", traversal)
+        gpu_ctx.set_option("prune", prune)
+        t_g, tri_g = gpu_ctx.primary_hits()
+        assert (tri_g == tri_o).all() and (bits(t_g) == bits(t_o)).all(), (cfg, traversal, prune)
+    gpu_ctx.set_option("traversal", 3); gpu_ctx.set_option("prune", 2)
+
+
 def random_rays(s, n, seed):
     rng = np.random.default_rng(seed)
     lo, hi = s.node_min[:3], s.node_max[:3]
