@@ -56,6 +56,21 @@ def test_primary_hits_of_every_configuration_at_full_size(gpu_ctx, ptx, orc, cfg
     gpu_ctx.set_option("traversal", 3); gpu_ctx.set_option("prune", 2)
 
 
+@pytest.mark.parametrize("cfg", ["C2", "C3", "C4"])
+def test_whole_frame_at_full_size_equals_the_oracle(gpu_ctx, ptx, orc, cfg):
+    """Every pixel of one whole frame at the configuration's own size and the four reference counters, library defaults against the
+    oracle (5 - 10 s of host cores each; the headline and C5 the same way by tools/full_frame_vs_oracle.py, 50 and 200 s:
+    profiles/r03_full_frames_vs_oracle.json)."""
+    c = ptx.CONFIGS[cfg]
+    s, p = setup(gpu_ctx, ptx, c["scene"], c["width"], c["height"], spp=c["sample_count"], bounces=c["max_path_length"])
+    gpu_ctx.render_frames([1003], first_frame_number=3)
+    got, gc = gpu_ctx.read_sum(), gpu_ctx.counters()
+    want, oc = orc.render_frame(s, p, 1003, nthreads=min(16, orc.max_threads()))
+    assert (bits(got) == bits(want)).all()
+    for key in ("samples", "rays", "ray_hits", "light_attempts"):
+        assert gc[key] == oc[key], key
+
+
 def random_rays(s, n, seed):
     rng = np.random.default_rng(seed)
     lo, hi = s.node_min[:3], s.node_max[:3]
